@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the FlowNet2 custom-layer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path, forward + backward, over one batch of 8 synthetic image
+pairs at 384x512 (BASELINE.json):
+    Correlation  fwd+bwd  in 8x256x48x64 fp32, FlowNetC parameters (20,1,20,1,2)  (configs[1])
+    Resample2d   fwd+bwd  img 8x3x384x512, flow 8x2x384x512
+    ChannelNorm  fwd+bwd  8x3x384x512
+all through the reference-named pybind modules (correlation_cuda / resample2d_cuda /
+channelnorm_cuda -> C ABI -> gfx950 HIP kernels).  Inputs are resident in HBM before the timed
+region.  N ranks = N independent batches (the path shards over the batch with no data-path
+collective: weak scaling); value = image pairs processed by all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the correlation forward kernel (the kernel
+BASELINE.json's metric names): achieved = algorithmic bytes of one launch (SURVEY.md 8d:
+2*B*C*H*W*4 read + B*441*H*W*4 written = 93 683 712 B) / mean launch duration, measured with HIP
+events on the launch stream inside the timed steps.  `cpu_baseline` times the CPU oracle
+(oracle/, a restatement of the reference kernels; the reference itself has no CPU path) on a
+bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "flownet2-pytorch_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+CORR = dict(B=8, C=256, H=48, W=64, pad=20, k=1, md=20, s1=1, s2=2)
+IMG = dict(B=8, C=3, H=384, W=512)
+
+
+def corr_fwd_bytes(B=CORR["B"]):
+    return 2 * B * CORR["C"] * CORR["H"] * CORR["W"] * 4 + B * 441 * CORR["H"] * CORR["W"] * 4
+
+
+def algorithmic_bytes(B=8):
+    """SURVEY.md 8(d) per-call figures (fp32)."""
+    hw_c = B * CORR["C"] * CORR["H"] * CORR["W"] * 4
+    out_c = B * 441 * CORR["H"] * CORR["W"] * 4
+    px = B * IMG["H"] * IMG["W"] * 4
+    return {
+        "corr_fwd": 2 * hw_c + out_c,
+        "corr_bwd": out_c + 2 * hw_c + 2 * hw_c,
+        "resample_fwd": (3 + 2 + 3) * px,
+        "resample_bwd": (3 + 2 + 3) * px + (3 + 2) * px,
+        "chnorm_fwd": (3 + 1) * px,
+        "chnorm_bwd": (3 + 1 + 1) * px + 3 * px,
+    }
+
+
+class HotPath:
+    """Device-resident synthetic inputs + one fwd/bwd pass through the three extension modules."""
+
+    def __init__(self, dev, seed):
+        import channelnorm_cuda
+        import correlation_cuda
+        import resample2d_cuda
+        self.m_corr, self.m_res, self.m_cn = correlation_cuda, resample2d_cuda, channelnorm_cuda
+        g = torch.Generator().manual_seed(seed)
+        c, i = CORR, IMG
+        self.in1 = torch.randn(c["B"], c["C"], c["H"], c["W"], generator=g).to(dev)
+        self.in2 = torch.randn(c["B"], c["C"], c["H"], c["W"], generator=g).to(dev)
+        self.gcorr = torch.randn(c["B"], 441, c["H"], c["W"], generator=g).to(dev)
+        self.img = (torch.rand(i["B"], 3, i["H"], i["W"], generator=g) - 0.5).to(dev)
+        flow = torch.randn(i["B"], 2, i["H"], i["W"], generator=g) * 4.0
+        idx = torch.randint(0, flow.numel(), (flow.numel() // 100,), generator=g)
+        flow.view(-1)[idx] *= 20.0
+        self.flow = flow.to(dev)
+        self.gwarp = torch.randn(i["B"], 3, i["H"], i["W"], generator=g).to(dev)
+        self.gnorm = torch.randn(i["B"], 1, i["H"], i["W"], generator=g).to(dev)
+        self.cparams = (c["pad"], c["k"], c["md"], c["s1"], c["s2"], 1)
+        e = self.in1.new_empty
+        self.scr1, self.scr2 = e(0), e(0)
+        self.out, self.g1, self.g2 = e(0), e(0), e(0)
+        self.warped = torch.zeros_like(self.img)
+        self.gimg = torch.zeros_like(self.img)
+        self.gflow = torch.zeros_like(self.flow)
+        self.norm = torch.zeros(i["B"], 1, i["H"], i["W"], device=dev)
+        self.gdiff = torch.zeros_like(self.img)
+        self.ev = None
+
+    def corr_fwd(self):
+        self.m_corr.forward(self.in1, self.in2, self.scr1, self.scr2, self.out, *self.cparams)
+
+    def corr_bwd(self):
+        self.m_corr.backward(self.in1, self.in2, self.scr1, self.scr2, self.gcorr, self.g1, self.g2, *self.cparams)
+
+    def step(self, events=None):
+        """fwd + bwd of the three layers.  `events`, if given, collects (start, stop) HIP event
+        pairs around each op on the current stream."""
+        def timed(name, fn):
+            if events is None:
+                fn()
+                return
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            events.setdefault(name, []).append((s, e))
+        timed("corr_fwd", self.corr_fwd)
+        timed("corr_bwd", self.corr_bwd)
+        timed("resample_fwd", lambda: self.m_res.forward(self.img, self.flow, self.warped, 1, True))
+        timed("chnorm_fwd", lambda: self.m_cn.forward(self.warped, self.norm, 2))
+        timed("chnorm_bwd", lambda: self.m_cn.backward(self.warped, self.norm, self.gnorm, self.gdiff, 2))
+
+        def res_bwd():
+            self.gimg.zero_()   # the reference wrapper zero-fills grad_input1 every call (resample2d.py:31)
+            self.m_res.backward(self.img, self.flow, self.gwarp, self.gimg, self.gflow, 1, True)
+        timed("resample_bwd", res_bwd)
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle (a C restatement of the reference kernels, OpenMP over the host cores) on a bounded
+    sample: the same workload at batch 1 (one image pair), repeated while time allows."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    rng = np.random.default_rng(0)
+    c, i = CORR, IMG
+    a = rng.standard_normal((1, c["C"], c["H"], c["W"])).astype(np.float32)
+    b = rng.standard_normal((1, c["C"], c["H"], c["W"])).astype(np.float32)
+    go = rng.standard_normal((1, 441, c["H"], c["W"])).astype(np.float32)
+    img = (rng.random((1, 3, i["H"], i["W"])) - 0.5).astype(np.float32)
+    flow = (rng.standard_normal((1, 2, i["H"], i["W"])) * 4).astype(np.float32)
+    gw = rng.standard_normal((1, 3, i["H"], i["W"])).astype(np.float32)
+    gn = rng.standard_normal((1, 1, i["H"], i["W"])).astype(np.float32)
+    p = (c["pad"], c["k"], c["md"], c["s1"], c["s2"])
+
+    def one_pair():
+        orc.corr_fwd(a, b, *p)
+        orc.corr_bwd(a, b, go, *p)
+        w = orc.resample_fwd(img, flow)
+        n = orc.chnorm_fwd(w)
+        orc.chnorm_bwd(w, n, gn)
+        orc.resample_bwd(img, flow, gw)
+
+    t0 = time.perf_counter()
+    one_pair()                      # warm-up (page faults, OpenMP pool)
+    warm = time.perf_counter() - t0
+    times = []
+    budget = max(0.0, max_seconds - warm)
+    while True:
+        t0 = time.perf_counter()
+        one_pair()
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 5 or sum(times) + times[-1] > budget:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {
+        "value": round(1.0 / med, 4),
+        "unit": "image-pairs/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"batch-1 slice of the workload (1 pair: corr 1x256x48x64 fwd+bwd, resample2d+channelnorm "
+                  f"1x3x384x512 fwd+bwd), median of {len(times)} runs after 1 warm-up, fp32, OpenMP on all host cores",
+        "seconds_per_pair": round(med, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only implementation"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
+
+    hp = HotPath(dev, seed=1234 + rank)   # every rank its own batch: no cross-GPU dependence
+    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+        hp.step()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    events = {}
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.step(events)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
+        ab = algorithmic_bytes(CORR["B"])
+        kernels = {k: {"ms": round(ms, 5), "algorithmic_bytes": ab[k],
+                       "achieved_GBps": round(ab[k] / (ms * 1e-3) / 1e9, 2),
+                       "frac_of_8TBps": round(ab[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                   for k, ms in per_op_ms.items()}
+        cf = kernels["corr_fwd"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "corr_fwd_hbm_traffic.json")
+        if os.path.exists(tpath):   # PMC pass (separate rocprofv3 --pmc run), bytes per launch, corrected per the guide
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        pairs = CORR["B"] * args.steps * world
+        line = {
+            "metric": "image-pairs/sec",
+            "value": round(pairs / elapsed, 3),
+            "unit": "image-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "FlowNet2 custom-layer hot path fwd+bwd, bs8 @384x512: Correlation 8x256x48x64 "
+                            "(20,1,20,1,2) [BASELINE configs[1]] + Resample2d 8x3x384x512 + ChannelNorm 8x3x384x512",
+                "pairs_per_step_per_gpu": CORR["B"],
+                "sharding": "batch over ranks, no data-path collective",
+            },
+            "roofline": {
+                "kernel": "correlation forward (corr_fwd_mfma_f32)",
+                "bound": "hbm",
+                "achieved": cf["achieved_GBps"],
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(cf["achieved_GBps"] / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "launch_ms": cf["ms"],
+                "algorithmic_bytes": cf["algorithmic_bytes"],
+            },
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+// channelnorm_cuda.cpp -- pybind module `channelnorm_cuda` (drop-in for the reference's module,
+// channelnorm_cuda.cc:6-30).  norm_deg is accepted and ignored, as by the reference kernels.
+#include "binding_common.h"
+
+using namespace fn2b;
+
+// channelnorm_cuda_forward (channelnorm_cuda.cc:6-14)
+int channelnorm_forward_hip(at::Tensor &input1, at::Tensor &output, int norm_deg)
+{
+    (void)norm_deg;
+    const char *op = "channelnorm_cuda.forward";
+    check_gpu(input1, op, "input1");
+    check_same(input1, output, op, "output");
+    TORCH_CHECK(input1.dim() == 4 && output.dim() == 4, op, ": tensors must be 4-D");
+    const int dt = dtype_of(input1, op);
+    const int B = input1.size(0), C = input1.size(1), H = input1.size(2), W = input1.size(3);
+    TORCH_CHECK(output.size(0) == B && output.size(1) == 1 && output.size(2) == H && output.size(3) == W, op,
+                ": output has shape ", output.sizes(), ", expected [", B, ", 1, ", H, ", ", W, "]");
+    TORCH_CHECK(output.is_contiguous(), op, ": output must be contiguous");
+    c10::hip::HIPGuard guard(input1.device());
+    at::Tensor a = input1.contiguous();
+    check_rc(fn2_channelnorm_forward(a.data_ptr(), output.data_ptr(), dt, B, C, H, W, current_stream(input1)), op);
+    return 1;
+}
+
+// channelnorm_cuda_backward (channelnorm_cuda.cc:16-25).  gradOutput's strides are honoured (the
+// reference indexes it as if contiguous, channelnorm_kernel.cu:92 -- SURVEY.md 5, last bullet).
+int channelnorm_backward_hip(at::Tensor &input1, at::Tensor &output, at::Tensor &gradOutput, at::Tensor &gradInput1,
+                             int norm_deg)
+{
+    (void)norm_deg;
+    const char *op = "channelnorm_cuda.backward";
+    check_gpu(input1, op, "input1");
+    check_same(input1, output, op, "output");
+    check_same(input1, gradOutput, op, "gradOutput");
+    check_same(input1, gradInput1, op, "gradInput1");
+    TORCH_CHECK(input1.dim() == 4 && output.dim() == 4 && gradOutput.dim() == 4, op, ": tensors must be 4-D");
+    const int dt = dtype_of(input1, op);
+    const int B = input1.size(0), C = input1.size(1), H = input1.size(2), W = input1.size(3);
+    TORCH_CHECK(output.size(0) == B && output.size(1) == 1 && output.size(2) == H && output.size(3) == W, op,
+                ": output has shape ", output.sizes());
+    TORCH_CHECK(gradOutput.sizes() == output.sizes(), op, ": gradOutput ", gradOutput.sizes(), " must match output ",
+                output.sizes());
+    TORCH_CHECK(gradInput1.sizes() == input1.sizes() && gradInput1.is_contiguous(), op,
+                ": gradInput1 must be contiguous and shaped like input1");
+    c10::hip::HIPGuard guard(input1.device());
+    at::Tensor a = input1.contiguous(), o = output.contiguous();
+    int64_t gs[4];
+    for (int i = 0; i < 4; ++i) gs[i] = gradOutput.stride(i);
+    check_rc(fn2_channelnorm_backward(a.data_ptr(), o.data_ptr(), gradOutput.data_ptr(), gs, gradInput1.data_ptr(), dt,
+                                      B, C, H, W, current_stream(input1)), op);
+    return 1;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "FlowNet2 ChannelNorm layer, gfx950 HIP kernels (drop-in for the reference channelnorm_cuda)";
+    m.def("forward", &channelnorm_forward_hip, "Channel norm forward (HIP, gfx950)");
+    m.def("backward", &channelnorm_backward_hip, "Channel norm backward (HIP, gfx950)");
+}

@@ -1,0 +1,74 @@
+// correlation_cuda.cpp -- pybind module `correlation_cuda` (drop-in for the reference's module of
+// the same name, correlation_cuda.cc:10-172): forward / backward with the reference's positional
+// signature, tensors owned by Python, outputs resized in place.
+#include "binding_common.h"
+
+using namespace fn2b;
+
+// correlation_forward_cuda (correlation_cuda.cc:10-87).  rInput1 / rInput2 are the reference's
+// padded-NHWC scratch tensors; this implementation needs no scratch and leaves them untouched.
+int correlation_forward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &rInput1, at::Tensor &rInput2,
+                            at::Tensor &output, int pad_size, int kernel_size, int max_displacement, int stride1,
+                            int stride2, int corr_type_multiply)
+{
+    (void)rInput1; (void)rInput2; (void)corr_type_multiply; // accepted, unused (as in the reference kernels)
+    const char *op = "correlation_cuda.forward";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    check_same(input1, output, op, "output");
+    TORCH_CHECK(input1.dim() == 4 && input2.dim() == 4, op, ": inputs must be 4-D (N, C, H, W)");
+    TORCH_CHECK(input1.sizes() == input2.sizes(), op, ": input1 ", input1.sizes(), " and input2 ", input2.sizes(),
+                " must have the same shape");
+    const int dt = dtype_of(input1, op);
+    const int B = input1.size(0), C = input1.size(1), H = input1.size(2), W = input1.size(3);
+    int nOut = 0, oH = 0, oW = 0;
+    check_rc(fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut, &oH,
+                                          &oW), op);
+    c10::hip::HIPGuard guard(input1.device());
+    at::Tensor a = input1.contiguous(), b = input2.contiguous();
+    output.resize_({B, nOut, oH, oW}); // correlation_cuda.cc:38; fully written by the kernel, no fill_(0)
+    TORCH_CHECK(output.is_contiguous(), op, ": output must be contiguous");
+    check_rc(fn2_correlation_forward(a.data_ptr(), b.data_ptr(), output.data_ptr(), dt, B, C, H, W, pad_size,
+                                     kernel_size, max_displacement, stride1, stride2, current_stream(input1)), op);
+    return 1;
+}
+
+// correlation_backward_cuda (correlation_cuda.cc:89-167)
+int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &rInput1, at::Tensor &rInput2,
+                             at::Tensor &gradOutput, at::Tensor &gradInput1, at::Tensor &gradInput2, int pad_size,
+                             int kernel_size, int max_displacement, int stride1, int stride2, int corr_type_multiply)
+{
+    (void)rInput1; (void)rInput2; (void)corr_type_multiply;
+    const char *op = "correlation_cuda.backward";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    check_same(input1, gradOutput, op, "gradOutput");
+    check_same(input1, gradInput1, op, "gradInput1");
+    check_same(input1, gradInput2, op, "gradInput2");
+    TORCH_CHECK(input1.dim() == 4 && input1.sizes() == input2.sizes(), op, ": inputs must be 4-D and equally shaped");
+    const int dt = dtype_of(input1, op);
+    const int B = input1.size(0), C = input1.size(1), H = input1.size(2), W = input1.size(3);
+    int nOut = 0, oH = 0, oW = 0;
+    check_rc(fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut, &oH,
+                                          &oW), op);
+    TORCH_CHECK(gradOutput.dim() == 4 && gradOutput.size(0) == B && gradOutput.size(1) == nOut &&
+                    gradOutput.size(2) == oH && gradOutput.size(3) == oW,
+                op, ": gradOutput has shape ", gradOutput.sizes(), ", expected [", B, ", ", nOut, ", ", oH, ", ", oW, "]");
+    c10::hip::HIPGuard guard(input1.device());
+    at::Tensor a = input1.contiguous(), b = input2.contiguous();
+    at::Tensor go = gradOutput.contiguous(); // the reference assumes contiguity without checking (SURVEY.md b)
+    gradInput1.resize_({B, C, H, W});        // correlation_cuda.cc:108-109; fully written, no fill_(0)
+    gradInput2.resize_({B, C, H, W});
+    TORCH_CHECK(gradInput1.is_contiguous() && gradInput2.is_contiguous(), op, ": gradInputs must be contiguous");
+    check_rc(fn2_correlation_backward(a.data_ptr(), b.data_ptr(), go.data_ptr(), gradInput1.data_ptr(),
+                                      gradInput2.data_ptr(), dt, B, C, H, W, pad_size, kernel_size, max_displacement,
+                                      stride1, stride2, current_stream(input1)), op);
+    return 1;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "FlowNet2 correlation layer, gfx950 HIP kernels (drop-in for the reference correlation_cuda)";
+    m.def("forward", &correlation_forward_hip, "Correlation forward (HIP, gfx950)");
+    m.def("backward", &correlation_backward_hip, "Correlation backward (HIP, gfx950)");
+}

@@ -1,0 +1,77 @@
+// resample2d_cuda.cpp -- pybind module `resample2d_cuda` (drop-in for the reference's module,
+// resample2d_cuda.cc:6-31).  float32 only, as in the reference (resample2d_kernel.cu:221-230).
+#include "binding_common.h"
+
+using namespace fn2b;
+
+static void strides4(const at::Tensor &t, int64_t s[4])
+{
+    for (int i = 0; i < 4; ++i) s[i] = t.stride(i);
+}
+
+// resample2d_cuda_forward (resample2d_cuda.cc:6-13).  `output` is allocated (zero-filled) by the
+// Python wrapper with shape (B_flow, C_img, H_flow, W_flow) (resample2d.py:16-18).
+int resample2d_forward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &output, int kernel_size, bool bilinear)
+{
+    const char *op = "resample2d_cuda.forward";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    check_same(input1, output, op, "output");
+    TORCH_CHECK(input1.scalar_type() == at::kFloat, op, ": float32 tensors expected, got ", input1.scalar_type());
+    TORCH_CHECK(input1.dim() == 4 && input2.dim() == 4 && output.dim() == 4, op, ": tensors must be 4-D");
+    TORCH_CHECK(input2.size(1) == 2, op, ": input2 (flow) must have 2 channels, got ", input2.size(1));
+    const int B = output.size(0), C = output.size(1), H = output.size(2), W = output.size(3);
+    TORCH_CHECK(input2.size(0) == B && input2.size(2) == H && input2.size(3) == W, op, ": flow ", input2.sizes(),
+                " does not match output ", output.sizes());
+    TORCH_CHECK(input1.size(0) == B && input1.size(1) == C, op, ": input1 ", input1.sizes(), " does not match output ",
+                output.sizes());
+    TORCH_CHECK(output.is_contiguous(), op, ": output must be contiguous");
+    c10::hip::HIPGuard guard(input1.device());
+    at::Tensor flow = input2.contiguous();
+    int64_t is[4];
+    strides4(input1, is); // honoured by the kernel, like the reference's DIM3_INDEX
+    check_rc(fn2_resample2d_forward(input1.data_ptr<float>(), is, flow.data_ptr<float>(), output.data_ptr<float>(), B,
+                                    C, (int)input1.size(2), (int)input1.size(3), H, W, kernel_size, bilinear ? 1 : 0,
+                                    current_stream(input1)), op);
+    return 1;
+}
+
+// resample2d_cuda_backward (resample2d_cuda.cc:15-24).  gradInput1 arrives zero-filled and is
+// accumulated into; gradInput2 is overwritten (resample2d.py:31-36).
+int resample2d_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &gradOutput, at::Tensor &gradInput1,
+                            at::Tensor &gradInput2, int kernel_size, bool bilinear)
+{
+    const char *op = "resample2d_cuda.backward";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    check_same(input1, gradOutput, op, "gradOutput");
+    check_same(input1, gradInput1, op, "gradInput1");
+    check_same(input1, gradInput2, op, "gradInput2");
+    TORCH_CHECK(input1.scalar_type() == at::kFloat, op, ": float32 tensors expected, got ", input1.scalar_type());
+    TORCH_CHECK(input1.dim() == 4 && input2.dim() == 4 && gradOutput.dim() == 4, op, ": tensors must be 4-D");
+    const int B = gradOutput.size(0), C = gradOutput.size(1), H = gradOutput.size(2), W = gradOutput.size(3);
+    TORCH_CHECK(input2.size(0) == B && input2.size(1) == 2 && input2.size(2) == H && input2.size(3) == W, op,
+                ": flow ", input2.sizes(), " does not match gradOutput ", gradOutput.sizes());
+    TORCH_CHECK(input1.size(0) == B && input1.size(1) == C, op, ": input1 ", input1.sizes(),
+                " does not match gradOutput ", gradOutput.sizes());
+    TORCH_CHECK(gradInput1.sizes() == input1.sizes() && gradInput1.is_contiguous(), op,
+                ": gradInput1 must be contiguous and shaped like input1");
+    TORCH_CHECK(gradInput2.sizes() == input2.sizes() && gradInput2.is_contiguous(), op,
+                ": gradInput2 must be contiguous and shaped like input2");
+    c10::hip::HIPGuard guard(input1.device());
+    at::Tensor flow = input2.contiguous(), go = gradOutput.contiguous();
+    int64_t is[4];
+    strides4(input1, is);
+    check_rc(fn2_resample2d_backward(input1.data_ptr<float>(), is, flow.data_ptr<float>(), go.data_ptr<float>(),
+                                     gradInput1.data_ptr<float>(), gradInput2.data_ptr<float>(), B, C,
+                                     (int)input1.size(2), (int)input1.size(3), H, W, kernel_size, bilinear ? 1 : 0,
+                                     current_stream(input1)), op);
+    return 1;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "FlowNet2 Resample2d layer, gfx950 HIP kernels (drop-in for the reference resample2d_cuda)";
+    m.def("forward", &resample2d_forward_hip, "Resample2D forward (HIP, gfx950)");
+    m.def("backward", &resample2d_backward_hip, "Resample2D backward (HIP, gfx950)");
+}

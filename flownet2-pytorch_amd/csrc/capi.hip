@@ -1,0 +1,109 @@
+// capi.hip -- C-ABI entry points of libflownet2_hip.so that are not tied to one kernel file:
+// error strings, shape math and the correlation dispatcher (include/flownet2_hip.h).
+#include <math.h>
+
+#include "corr_params.h"
+
+
+extern "C" const char *fn2_strerror(int code)
+{
+    switch (code) {
+    case FN2_OK: return "ok";
+    case FN2_EINVAL: return "flownet2_hip: invalid shape or parameter";
+    case FN2_EDTYPE: return "flownet2_hip: dtype not supported by this op";
+    case FN2_EALIGN: return "flownet2_hip: pointer not aligned to its element size";
+    case FN2_EUNSUPPORTED: return "flownet2_hip: parameter combination the reference leaves undefined";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "flownet2_hip: unknown error";
+}
+
+extern "C" int fn2_abi_version(void) { return FN2_ABI_VERSION; }
+
+// correlation_cuda.cc:19-34
+extern "C" int fn2_correlation_output_shape(int H, int W, int pad_size, int kernel_size, int max_displacement,
+                                            int stride1, int stride2, int *nOut, int *oH, int *oW)
+{
+    if (H < 1 || W < 1 || pad_size < 0 || kernel_size < 1 || max_displacement < 0 || stride1 < 1 || stride2 < 1)
+        return FN2_EINVAL;
+    const int kernel_radius = (kernel_size - 1) / 2;
+    const int border_radius = kernel_radius + max_displacement;
+    const int pH = H + 2 * pad_size, pW = W + 2 * pad_size;
+    const int d = (max_displacement / stride2) * 2 + 1;
+    const int oh = (int)ceilf((float)(pH - 2 * border_radius) / (float)stride1);
+    const int ow = (int)ceilf((float)(pW - 2 * border_radius) / (float)stride1);
+    if (oh < 1 || ow < 1) return FN2_EINVAL;
+    if (nOut) *nOut = d * d;
+    if (oH) *oH = oh;
+    if (oW) *oW = ow;
+    return FN2_OK;
+}
+
+extern "C" int fn2_correlation_forward_ex(const void *in1, const void *in2, void *out, int dtype,
+                                          int B, int C, int H, int W,
+                                          int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                          int algo, void *stream)
+{
+    using namespace fn2;
+    const size_t es = dtype_size(dtype);
+    if (!es) return FN2_EDTYPE;
+    CorrP p;
+    int rc = corr_make_params(p, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2);
+    if (rc != FN2_OK) return rc;
+    if (B == 0) return FN2_OK;
+    if (!in1 || !in2 || !out) return FN2_EINVAL;
+    if (!aligned(in1, es) || !aligned(in2, es) || !aligned(out, es)) return FN2_EALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool mfma_ok = corr_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                                  stride2) && aligned(in1, 8) && aligned(in2, 8);
+    if (algo == FN2_CORR_MFMA_F32 && !mfma_ok) return FN2_EUNSUPPORTED;
+    if (algo == FN2_CORR_MFMA_F32 || (algo == FN2_CORR_AUTO && mfma_ok))
+        return corr_forward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
+                                     static_cast<float *>(out), B, C, H, W, max_displacement, s);
+    if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
+    return corr_forward_direct(in1, in2, out, dtype, p, s);
+}
+
+extern "C" int fn2_correlation_forward(const void *in1, const void *in2, void *out, int dtype,
+                                       int B, int C, int H, int W,
+                                       int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                       void *stream)
+{
+    return fn2_correlation_forward_ex(in1, in2, out, dtype, B, C, H, W, pad_size, kernel_size, max_displacement,
+                                      stride1, stride2, FN2_CORR_AUTO, stream);
+}
+
+extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *grad_out,
+                                           void *grad_in1, void *grad_in2, int dtype,
+                                           int B, int C, int H, int W,
+                                           int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                           int algo, void *stream)
+{
+    using namespace fn2;
+    const size_t es = dtype_size(dtype);
+    if (!es) return FN2_EDTYPE;
+    CorrP p;
+    int rc = corr_make_params(p, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2);
+    if (rc != FN2_OK) return rc;
+    // the reference's backward indexes (and writes) out of bounds for stride1 != 1
+    if (stride1 != 1) return FN2_EUNSUPPORTED;
+    if (B == 0) return FN2_OK;
+    if (!in1 || !in2 || !grad_out || !grad_in1 || !grad_in2) return FN2_EINVAL;
+    if (!aligned(in1, es) || !aligned(in2, es) || !aligned(grad_out, es) || !aligned(grad_in1, es) ||
+        !aligned(grad_in2, es))
+        return FN2_EALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EUNSUPPORTED;
+    return corr_backward_direct(in1, in2, grad_out, grad_in1, grad_in2, dtype, p, s);
+}
+
+extern "C" int fn2_correlation_backward(const void *in1, const void *in2, const void *grad_out,
+                                        void *grad_in1, void *grad_in2, int dtype,
+                                        int B, int C, int H, int W,
+                                        int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                        void *stream)
+{
+    return fn2_correlation_backward_ex(in1, in2, grad_out, grad_in1, grad_in2, dtype, B, C, H, W, pad_size,
+                                       kernel_size, max_displacement, stride1, stride2, FN2_CORR_AUTO, stream);
+}

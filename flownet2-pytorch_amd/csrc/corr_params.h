@@ -1,0 +1,21 @@
+// corr_params.h -- correlation parameter block shared by the dispatcher and the kernel files.
+#pragma once
+#include "fn2_common.h"
+
+namespace fn2 {
+
+struct CorrP {
+    int B, C, H, W;            // input1 / input2 shape (NCHW)
+    int pad, k, md, s1, s2;    // pad_size, kernel_size, max_displacement, stride1, stride2
+    int kr, dr, D, nOut, oH, oW;
+};
+
+int corr_make_params(CorrP &p, int B, int C, int H, int W, int pad, int k, int md, int s1, int s2);
+int corr_forward_direct(const void *in1, const void *in2, void *out, int dtype, const CorrP &p, hipStream_t s);
+int corr_backward_direct(const void *in1, const void *in2, const void *gout, void *g1, void *g2, int dtype,
+                         const CorrP &p, hipStream_t s);
+bool corr_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
+int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
+                          hipStream_t s);
+
+} // namespace fn2

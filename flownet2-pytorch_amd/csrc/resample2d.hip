@@ -1,0 +1,250 @@
+// resample2d.hip -- Resample2d (bilinear / nearest flow warp) forward and backward for gfx950.
+//
+// Replaces reference kernels kernel_resample2d_update_output (resample2d_kernel.cu:15-72),
+// kernel_resample2d_backward_input1 (:75-125) and kernel_resample2d_backward_input2 (:127-198).
+//
+// HBM-bound gathers.  Unlike the reference (one thread per output ELEMENT: the flow is re-read
+// and the weights re-derived once per channel), one lane owns PX consecutive output pixels and
+// walks the image channels: flow is read once with a 16 B load, weights / corner offsets are
+// formed once, every output plane gets a coalesced 16 B store.  Algorithmic bytes (fp32):
+//   fwd  (2C + 2) * B*H*W * 4      bwd  (3C + 4) * B*H*W * 4  (+ the caller's zero-fill of grad_img)
+// The backward pass is ONE kernel (the reference launches two, each re-reading flow, grad_out and
+// the image): per pixel it scatters grad_out into the four corners of grad_img with hardware fp32
+// atomics and forms both flow-gradient components from the same loaded corners.
+// Arithmetic order follows the reference so the gather results are bit-identical to its source
+// semantics: bilinear weights in double, each term rounded to float, float accumulation.
+#include "fn2_common.h"
+
+namespace fn2 {
+
+typedef float __attribute__((ext_vector_type(4))) f4;
+
+struct ImgStrides { long b, c, h, w; };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// int(floor(xf)) with CUDA's saturating float->int conversion (cvt.rzi.s32.f32; NaN -> 0).
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483520.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+__device__ __forceinline__ int d2i_sat(double v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// ---------------------------------------------------------------- forward
+template <int PX>
+__global__ __launch_bounds__(256) void resample_fwd_kernel(const float *__restrict__ img, ImgStrides is,
+                                                           const float *__restrict__ flow, float *__restrict__ out,
+                                                           int C, int Hi, int Wi, int H, int W, long ngroups,
+                                                           int bilinear)
+{
+    const long HW = (long)H * W;
+    const int gpr = W / PX; // groups per row (W % PX == 0 when PX > 1)
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < ngroups; g += (long)gridDim.x * blockDim.x) {
+        const int x0 = (int)(g % gpr) * PX;
+        const long row = g / gpr;
+        const int y = (int)(row % H);
+        const int b = (int)(row / H);
+        const long fo = (long)b * 2 * HW + (long)y * W + x0;
+        float dx[PX], dy[PX];
+        if constexpr (PX == 4) {
+            const f4 vx = *reinterpret_cast<const f4 *>(flow + fo);
+            const f4 vy = *reinterpret_cast<const f4 *>(flow + fo + HW);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dx[i] = vx[i]; dy[i] = vy[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PX; ++i) { dx[i] = flow[fo + i]; dy[i] = flow[fo + HW + i]; }
+        }
+        long o00[PX], o01[PX], o10[PX], o11[PX];
+        double w00[PX], w01[PX], w10[PX], w11[PX];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const float xf = (float)(x0 + i) + dx[i], yf = (float)y + dy[i];
+            if (bilinear) {
+                const float fx = floorf(xf), fy = floorf(yf);
+                const float alpha = xf - fx, beta = yf - fy; // (:45-46)
+                // indices clamped with the OUTPUT dims (:49-52), then to the image (defensive)
+                const int xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1);
+                const int xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
+                const int yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1);
+                const int yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
+                o00[i] = yT * is.h + xL * is.w;
+                o01[i] = yT * is.h + xR * is.w;
+                o10[i] = yB * is.h + xL * is.w;
+                o11[i] = yB * is.h + xR * is.w;
+                const double a = (double)alpha, be = (double)beta; // "1." literals -> double (:56-59)
+                w00[i] = (1. - a) * (1. - be);
+                w01[i] = a * (1. - be);
+                w10[i] = (1. - a) * be;
+                w11[i] = a * be;
+            } else {
+                // nearest: floor(xf + 0.5) in double (:66-67)
+                const int xN = clampi(clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), 0, Wi - 1);
+                const int yN = clampi(clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1), 0, Hi - 1);
+                o00[i] = yN * is.h + xN * is.w;
+                o01[i] = o10[i] = o11[i] = o00[i];
+                w00[i] = 1.;
+                w01[i] = w10[i] = w11[i] = 0.;
+            }
+        }
+        const float *ib = img + (long)b * is.b;
+        float *ob = out + (long)b * C * HW + (long)y * W + x0;
+        for (int c = 0; c < C; ++c) {
+            const float *ic = ib + (long)c * is.c;
+            float v[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                if (bilinear) {
+                    float val = 0.0f;
+                    val = val + (float)(w00[i] * (double)ic[o00[i]]);
+                    val = val + (float)(w01[i] * (double)ic[o01[i]]);
+                    val = val + (float)(w10[i] * (double)ic[o10[i]]);
+                    val = val + (float)(w11[i] * (double)ic[o11[i]]);
+                    v[i] = val;
+                } else {
+                    v[i] = ic[o00[i]];
+                }
+            }
+            if constexpr (PX == 4) {
+                f4 r = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f4 *>(ob + (long)c * HW) = r;
+            } else {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) ob[(long)c * HW + i] = v[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward (fused input1 + input2)
+// One lane per output pixel, lanes along x (coalesced flow / grad_out reads, coalesced grad_flow
+// writes).  grad_img scatter: 4 fp32 hardware atomics per (pixel, channel); neighbouring lanes
+// mostly hit neighbouring addresses, which the memory pipeline merges per cache line.
+__global__ __launch_bounds__(256) void resample_bwd_kernel(const float *__restrict__ img, ImgStrides is,
+                                                           const float *__restrict__ flow,
+                                                           const float *__restrict__ gout,
+                                                           float *__restrict__ gimg, float *__restrict__ gflow,
+                                                           int C, int Hi, int Wi, int H, int W, long npix)
+{
+    const long HW = (long)H * W, HWi = (long)Hi * Wi;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(g % W);
+        const long row = g / W;
+        const int y = (int)(row % H);
+        const int b = (int)(row / H);
+        const long p = (long)y * W + x;
+        const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float fx = floorf(xf), fy = floorf(yf);
+        const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
+
+        // ---- grad_img: weights use truncation, alpha = xf - int(xf) (:105-106); corners clamped
+        //      with the INPUT1 dims (:108-114); all float math (:118-121).
+        const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
+        const int sxL = clampi(ixL, 0, Wi - 1), sxR = clampi(ixR, 0, Wi - 1);
+        const int syT = clampi(iyT, 0, Hi - 1), syB = clampi(iyB, 0, Hi - 1);
+        const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta);
+        const float s10 = (1 - alpha) * beta, s11 = alpha * beta;
+
+        // ---- grad_flow: corners clamped with the FLOW dims (:163-166) (then to the image, defensive)
+        const int gxL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), gxR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
+        const int gyT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), gyB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
+        const float gam_y = 1 - (xf - fx); // c == 1 branch: "gamma = 1 - (xf - floor(xf))" (:169)
+        const float gam_x = 1 - (yf - fy); // c == 0 branch (:182)
+        float out_dx = 0.0f, out_dy = 0.0f;
+
+        for (int ch = 0; ch < C; ++ch) {
+            const float go = gout[((long)b * C + ch) * HW + p];
+            float *G = gimg + ((long)b * C + ch) * HWi;
+            unsafeAtomicAdd(G + (long)syT * Wi + sxL, s00 * go);
+            unsafeAtomicAdd(G + (long)syT * Wi + sxR, s01 * go);
+            unsafeAtomicAdd(G + (long)syB * Wi + sxL, s10 * go);
+            unsafeAtomicAdd(G + (long)syB * Wi + sxR, s11 * go);
+
+            const float *I = img + (long)b * is.b + (long)ch * is.c;
+            const float iTL = I[gyT * is.h + gxL * is.w], iTR = I[gyT * is.h + gxR * is.w];
+            const float iBL = I[gyB * is.h + gxL * is.w], iBR = I[gyB * is.h + gxR * is.w];
+            // d/d(dy)  (:172-177)
+            out_dy = out_dy + (gam_y * go) * iBL;
+            out_dy = out_dy - (gam_y * go) * iTL;
+            out_dy = out_dy + ((1 - gam_y) * go) * iBR;
+            out_dy = out_dy - ((1 - gam_y) * go) * iTR;
+            // d/d(dx)  (:185-190)
+            out_dx = out_dx + (gam_x * go) * iTR;
+            out_dx = out_dx - (gam_x * go) * iTL;
+            out_dx = out_dx + ((1 - gam_x) * go) * iBR;
+            out_dx = out_dx - ((1 - gam_x) * go) * iBL;
+        }
+        gflow[(long)b * 2 * HW + p] = out_dx;
+        gflow[(long)b * 2 * HW + HW + p] = out_dy;
+    }
+}
+
+static inline unsigned stream_grid(long nthreads)
+{
+    long blocks = (nthreads + 255) / 256;
+    const long cap = 256L * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+} // namespace fn2
+
+extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
+                                      int B, int C, int Hi, int Wi, int H, int W,
+                                      int kernel_size, int bilinear, void *stream)
+{
+    using namespace fn2;
+    if (B < 0 || C < 0 || Hi < 1 || Wi < 1 || H < 0 || W < 0) return FN2_EINVAL;
+    if (kernel_size != 1) return FN2_EUNSUPPORTED;
+    if ((long)B * C * H * W == 0) return FN2_OK;
+    if (!img || !flow || !out) return FN2_EINVAL;
+    if (!aligned(img, 4) || !aligned(flow, 4) || !aligned(out, 4)) return FN2_EALIGN;
+    ImgStrides is;
+    if (img_strides) { is.b = img_strides[0]; is.c = img_strides[1]; is.h = img_strides[2]; is.w = img_strides[3]; }
+    else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long npix = (long)B * H * W;
+    if (W % 4 == 0 && aligned(flow, 16) && aligned(out, 16)) {
+        const long ng = npix / 4;
+        hipLaunchKernelGGL(resample_fwd_kernel<4>, dim3(stream_grid(ng)), dim3(256), 0, s, img, is, flow, out, C, Hi, Wi,
+                           H, W, ng, bilinear ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL(resample_fwd_kernel<1>, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, out, C, Hi,
+                           Wi, H, W, npix, bilinear ? 1 : 0);
+    }
+    return launch_status();
+}
+
+extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
+                                       const float *grad_out, float *grad_img, float *grad_flow,
+                                       int B, int C, int Hi, int Wi, int H, int W,
+                                       int kernel_size, int bilinear, void *stream)
+{
+    using namespace fn2;
+    (void)bilinear; // both reference backward kernels ignore the flag
+    if (B < 0 || C < 0 || Hi < 1 || Wi < 1 || H < 0 || W < 0) return FN2_EINVAL;
+    if (kernel_size != 1) return FN2_EUNSUPPORTED;
+    if ((long)B * H * W == 0) return FN2_OK;
+    if (!img || !flow || !grad_out || !grad_img || !grad_flow) return FN2_EINVAL;
+    if (!aligned(img, 4) || !aligned(flow, 4) || !aligned(grad_out, 4) || !aligned(grad_img, 4) || !aligned(grad_flow, 4))
+        return FN2_EALIGN;
+    ImgStrides is;
+    if (img_strides) { is.b = img_strides[0]; is.c = img_strides[1]; is.h = img_strides[2]; is.w = img_strides[3]; }
+    else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out, grad_img,
+                       grad_flow, C, Hi, Wi, H, W, npix);
+    return launch_status();
+}

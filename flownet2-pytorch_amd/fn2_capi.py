@@ -1,0 +1,89 @@
+"""ctypes view of the C ABI (include/flownet2_hip.h) for callers that hold raw device pointers --
+used by the parity tests and bench.py to reach entry points the pybind modules do not expose
+(e.g. the ``*_ex`` algorithm selectors).  Raises if libflownet2_hip.so has not been built: there
+is no fallback implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflownet2_hip.so")
+
+FN2_F32, FN2_F16, FN2_F64 = 0, 1, 2
+FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32 = 0, 1, 2
+
+EXPORTS = [
+    "fn2_strerror", "fn2_abi_version", "fn2_correlation_output_shape",
+    "fn2_correlation_forward", "fn2_correlation_forward_ex",
+    "fn2_correlation_backward", "fn2_correlation_backward_ex",
+    "fn2_resample2d_forward", "fn2_resample2d_backward",
+    "fn2_channelnorm_forward", "fn2_channelnorm_backward",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libflownet2_hip.so.  ``import torch`` first so that the HIP runtime torch already
+    mapped (same soname) is the one the kernels register with."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `python flownet2-pytorch_amd/build.py` "
+                               "(the HIP kernels are the only implementation)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.fn2_strerror.restype = ctypes.c_char_p
+        _lib.fn2_strerror.argtypes = [ctypes.c_int]
+        for name in EXPORTS[1:]:
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {lib().fn2_strerror(rc).decode()} (code {rc})")
+
+
+def _dtype_code(t):
+    import torch
+    return {torch.float32: FN2_F32, torch.float16: FN2_F16, torch.float64: FN2_F64}[t.dtype]
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def correlation_output_shape(H, W, pad, k, md, s1, s2):
+    n, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(lib().fn2_correlation_output_shape(H, W, pad, k, md, s1, s2, ctypes.byref(n), ctypes.byref(oh),
+                                             ctypes.byref(ow)), "fn2_correlation_output_shape")
+    return n.value, oh.value, ow.value
+
+
+def correlation_forward(in1, in2, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=None):
+    import torch
+    B, C, H, W = in1.shape
+    nOut, oH, oW = correlation_output_shape(H, W, pad, k, md, s1, s2)
+    if out is None:
+        out = torch.empty((B, nOut, oH, oW), dtype=in1.dtype, device=in1.device)
+    with torch.cuda.device_of(in1):
+        check(lib().fn2_correlation_forward_ex(_p(in1), _p(in2), _p(out), _dtype_code(in1), B, C, H, W, pad, k, md, s1,
+                                               s2, algo, _stream(in1)), "fn2_correlation_forward_ex")
+    return out
+
+
+def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO):
+    import torch
+    B, C, H, W = in1.shape
+    g1, g2 = torch.empty_like(in1), torch.empty_like(in2)
+    with torch.cuda.device_of(in1):
+        check(lib().fn2_correlation_backward_ex(_p(in1), _p(in2), _p(gout), _p(g1), _p(g2), _dtype_code(in1), B, C, H,
+                                                W, pad, k, md, s1, s2, algo, _stream(in1)),
+              "fn2_correlation_backward_ex")
+    return g1, g2

@@ -1,0 +1,43 @@
+"""ChannelNorm (per-pixel L2 norm over channels): autograd Function + Module over the
+``channelnorm_cuda`` extension.
+
+Same public names and signatures as the reference wrapper
+(networks/channelnorm_package/channelnorm.py:5-38): ``ChannelNormFunction.apply(input1, norm_deg)``
+and ``ChannelNorm(norm_deg=2)``.  ``norm_deg`` is stored and passed on but, as in the reference
+kernels, only the L2 norm is implemented.  The backward honours grad_output's strides (the
+reference reads the non-contiguous slice autograd hands it as if it were contiguous).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+import channelnorm_cuda  # built by flownet2-pytorch_amd/build.py; no fallback on purpose
+
+
+class ChannelNormFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input1, norm_deg=2):
+        assert input1.is_contiguous(), "input1 must be contiguous (reference channelnorm.py:9)"
+        batch, _, height, width = input1.size()
+        output = input1.new_zeros((batch, 1, height, width))
+        channelnorm_cuda.forward(input1, output, norm_deg)
+        ctx.save_for_backward(input1, output)
+        ctx.norm_deg = norm_deg
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input1, output = ctx.saved_tensors
+        grad_input1 = torch.zeros_like(input1)
+        channelnorm_cuda.backward(input1, output, grad_output, grad_input1, ctx.norm_deg)
+        return grad_input1, None
+
+
+class ChannelNorm(nn.Module):
+    def __init__(self, norm_deg=2):
+        super().__init__()
+        self.norm_deg = norm_deg
+
+    def forward(self, input1):
+        return ChannelNormFunction.apply(input1, self.norm_deg)

@@ -1,0 +1,60 @@
+"""Correlation layer: autograd Function + Module over the ``correlation_cuda`` extension.
+
+Same public names, argument order and defaults as the reference wrapper
+(networks/correlation_package/correlation.py:6-60): ``CorrelationFunction.apply(input1, input2,
+pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)`` and
+``Correlation(pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, corr_multiply=1)``.
+The extension is the gfx950 HIP implementation (csrc/binding/correlation_cuda.cpp); importing this
+module fails loudly if it has not been built.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+import correlation_cuda  # built by flownet2-pytorch_amd/build.py; no fallback on purpose
+
+
+class CorrelationFunction(Function):
+    """out[n, tj*D+ti, y, x] = mean_c in1[n,c,y',x'] * in2[n,c,y'+tj*s2,x'+ti*s2] (reference
+    correlation_cuda_kernel.cu:73-147); backward per :150-334."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2,
+                corr_multiply=1):
+        ctx.save_for_backward(input1, input2)
+        ctx.corr_params = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
+        with torch.cuda.device_of(input1):
+            # the extension sizes these in place (reference correlation.py:20-22); the two scratch
+            # tensors of the reference ABI stay empty, the HIP kernels need no padded copies
+            scratch1, scratch2, output = input1.new_empty(0), input2.new_empty(0), input1.new_empty(0)
+            correlation_cuda.forward(input1, input2, scratch1, scratch2, output, *ctx.corr_params)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        with torch.cuda.device_of(input1):
+            scratch1, scratch2 = input1.new_empty(0), input2.new_empty(0)
+            grad_input1, grad_input2 = input1.new_empty(0), input2.new_empty(0)
+            correlation_cuda.backward(input1, input2, scratch1, scratch2, grad_output, grad_input1, grad_input2,
+                                      *ctx.corr_params)
+        return (grad_input1, grad_input2) + (None,) * 6
+
+
+class Correlation(nn.Module):
+    def __init__(self, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, corr_multiply=1):
+        super().__init__()
+        self.pad_size = pad_size
+        self.kernel_size = kernel_size
+        self.max_displacement = max_displacement
+        self.stride1 = stride1
+        self.stride2 = stride2
+        self.corr_multiply = corr_multiply
+
+    def forward(self, input1, input2):
+        return CorrelationFunction.apply(input1, input2, self.pad_size, self.kernel_size, self.max_displacement,
+                                         self.stride1, self.stride2, self.corr_multiply)
+
+    def extra_repr(self):
+        return (f"pad_size={self.pad_size}, kernel_size={self.kernel_size}, max_displacement={self.max_displacement}, "
+                f"stride1={self.stride1}, stride2={self.stride2}")

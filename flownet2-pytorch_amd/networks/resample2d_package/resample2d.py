@@ -1,0 +1,49 @@
+"""Resample2d (flow warp): autograd Function + Module over the ``resample2d_cuda`` extension.
+
+Same public names and signatures as the reference wrapper
+(networks/resample2d_package/resample2d.py:5-49): ``Resample2dFunction.apply(input1, input2,
+kernel_size, bilinear)`` and ``Resample2d(kernel_size=1, bilinear=True)``; output shape is
+(B, C_img, H, W) with B, H, W taken from the flow (reference :16-18).  float32 only, as in the
+reference.  Unlike the reference Module (:48) the image is NOT made contiguous first: the HIP
+kernel honours input1's strides, which saves a full copy of the channel slice models.py:133
+passes in.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+import resample2d_cuda  # built by flownet2-pytorch_amd/build.py; no fallback on purpose
+
+
+class Resample2dFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input1, input2, kernel_size=1, bilinear=True):
+        assert input2.is_contiguous(), "flow must be contiguous (reference resample2d.py:10)"
+        ctx.save_for_backward(input1, input2)
+        ctx.kernel_size, ctx.bilinear = kernel_size, bilinear
+        channels = input1.size(1)
+        batch, _, height, width = input2.size()
+        output = input1.new_zeros((batch, channels, height, width))
+        resample2d_cuda.forward(input1, input2, output, kernel_size, bilinear)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero
+        grad_input1 = torch.zeros_like(input1, memory_format=torch.contiguous_format)
+        grad_input2 = torch.zeros_like(input2, memory_format=torch.contiguous_format)
+        resample2d_cuda.backward(input1, input2, grad_output, grad_input1, grad_input2, ctx.kernel_size, ctx.bilinear)
+        return grad_input1, grad_input2, None, None
+
+
+class Resample2d(nn.Module):
+    def __init__(self, kernel_size=1, bilinear=True):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.bilinear = bilinear
+
+    def forward(self, input1, input2):
+        return Resample2dFunction.apply(input1, input2, self.kernel_size, self.bilinear)

@@ -1,0 +1,139 @@
+/*
+ * flownet2_hip.h -- C ABI of libflownet2_hip.so: FlowNet2's three custom layers
+ * (Correlation, Resample2d, ChannelNorm) as hand-written gfx950 (MI355X) HIP kernels.
+ *
+ * This is the drop-in boundary.  The reference reaches its kernels through three pybind
+ * modules -- correlation_cuda, resample2d_cuda, channelnorm_cuda -- whose forward/backward
+ * take at::Tensor& (reference correlation_cuda.cc:169-172, resample2d_cuda.cc:28-31,
+ * channelnorm_cuda.cc:27-30) and call host launchers taking raw pointers, sizes, strides
+ * and a stream (correlation_cuda_kernel.cuh:7-91, resample2d_kernel.cuh:5-18,
+ * channelnorm_kernel.cuh:5-16).  The entry points below replace those launchers: plain
+ * pointers and integers, no torch types.  The same-named pybind modules in
+ * flownet2-pytorch_amd/csrc/binding/ sit on top (shape math, resize_, device guard,
+ * error translation), see INTEGRATION.md.
+ *
+ * Conventions
+ *  - all tensors are NCHW device memory of the element type `dtype` names;
+ *  - `stream` is a hipStream_t (passed as void* to keep this header HIP-free); work is
+ *    enqueued on it and never synchronised here (reference: at::cuda::getCurrentCUDAStream(),
+ *    correlation_cuda.cc:76, resample2d_kernel.cu:221, channelnorm_kernel.cu:113);
+ *  - the caller has made the right device current;
+ *  - return value: FN2_OK (0), a negative FN2_E* code for a rejected call (nothing was
+ *    launched), or a positive hipError_t from the launch (hipGetLastError()).  The
+ *    reference's launchers return 0 on cudaGetLastError()!=success and the binding raises
+ *    AT_ERROR("CUDA call failed") (correlation_cuda_kernel.cu:417-424, correlation_cuda.cc:81-83);
+ *    the bindings here raise RuntimeError with fn2_strerror(code);
+ *  - re-entrant, no global mutable state.
+ */
+#ifndef FLOWNET2_HIP_H
+#define FLOWNET2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FN2_ABI_VERSION 1
+
+/* element types (reference dispatch: AT_DISPATCH_FLOATING_TYPES_AND_HALF for correlation and
+ * channelnorm -- correlation_cuda_kernel.cu:386-415, channelnorm_kernel.cu:111,152; float only
+ * for resample2d -- resample2d_kernel.cu:221,269,298) */
+enum { FN2_F32 = 0, FN2_F16 = 1, FN2_F64 = 2 };
+
+enum {
+    FN2_OK = 0,
+    FN2_EINVAL = -1,      /* bad shape / parameter */
+    FN2_EDTYPE = -2,      /* dtype not supported by this op */
+    FN2_EALIGN = -3,      /* pointer not aligned to its element size */
+    FN2_EUNSUPPORTED = -4 /* parameter combination the reference itself leaves undefined */
+};
+
+/* correlation algorithm selector for fn2_correlation_forward_ex */
+enum {
+    FN2_CORR_AUTO = 0,    /* fastest kernel whose preconditions hold */
+    FN2_CORR_DIRECT = 1,  /* one-thread-per-output kernel, any parameters / dtype */
+    FN2_CORR_MFMA_F32 = 2 /* LDS-tiled v_mfma_f32_16x16x4_f32 kernel (f32, k=1, s1=1, s2=2, pad==md) */
+};
+
+const char *fn2_strerror(int code);
+int fn2_abi_version(void);
+
+/* Shape math of correlation_forward_cuda (correlation_cuda.cc:19-34):
+ * nOut = ((md/s2)*2+1)^2, oH = ceil((H + 2*pad - 2*((k-1)/2 + md)) / s1), likewise oW. */
+int fn2_correlation_output_shape(int H, int W, int pad_size, int kernel_size, int max_displacement,
+                                 int stride1, int stride2, int *nOut, int *oH, int *oW);
+
+/* Replaces correlation_forward_cuda_kernel (correlation_cuda_kernel.cuh:7-41; kernels
+ * correlation_cuda_kernel.cu:46-70 channels_first, :73-147 correlation_forward).
+ *   in1, in2 : B x C x H x W contiguous       out : B x nOut x oH x oW contiguous, fully written
+ * No rInput1/rInput2 scratch is needed (the reference's padded-NHWC copies are not
+ * materialised).  corr_type_multiply is accepted by the reference and unused; it is not part
+ * of this ABI.  Accumulation is fp32 for every dtype, as in the reference (:112,:124). */
+int fn2_correlation_forward(const void *in1, const void *in2, void *out, int dtype,
+                            int B, int C, int H, int W,
+                            int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                            void *stream);
+int fn2_correlation_forward_ex(const void *in1, const void *in2, void *out, int dtype,
+                               int B, int C, int H, int W,
+                               int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                               int algo, void *stream);
+
+/* Replaces correlation_backward_cuda_kernel (correlation_cuda_kernel.cuh:44-91; kernels
+ * correlation_cuda_kernel.cu:150-241 backward_input1, :243-334 backward_input2, host loops
+ * :522-554).  grad_out : B x nOut x oH x oW contiguous; grad_in1, grad_in2 : B x C x H x W,
+ * fully written (no pre-zeroing needed, unlike the reference :113-114 of correlation_cuda.cc).
+ * Like the reference this is only meaningful for stride1 == 1; other values
+ * return FN2_EUNSUPPORTED. */
+int fn2_correlation_backward(const void *in1, const void *in2, const void *grad_out,
+                             void *grad_in1, void *grad_in2, int dtype,
+                             int B, int C, int H, int W,
+                             int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                             void *stream);
+int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *grad_out,
+                                void *grad_in1, void *grad_in2, int dtype,
+                                int B, int C, int H, int W,
+                                int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                int algo, void *stream);
+
+/* Replaces resample2d_kernel_forward (resample2d_kernel.cuh:5-10; kernel
+ * resample2d_kernel.cu:15-72).  float32 only, like the reference.
+ *   img  : B x C x Hi x Wi with element strides img_strides[4] (NULL = contiguous); the
+ *          reference kernel honours input1's strides too (DIM3_INDEX), its Python wrapper
+ *          just never passes a strided tensor (resample2d.py:9,48)
+ *   flow : B x 2 x H x W contiguous (channel 0 = dx, 1 = dy)
+ *   out  : B x C x H x W contiguous, fully written
+ * kernel_size must be 1 (the reference reads out of bounds for larger values). */
+int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
+                           int B, int C, int Hi, int Wi, int H, int W,
+                           int kernel_size, int bilinear, void *stream);
+
+/* Replaces resample2d_kernel_backward (resample2d_kernel.cuh:12-18; kernels
+ * resample2d_kernel.cu:75-125 backward_input1, :127-198 backward_input2).
+ *   grad_out : B x C x H x W contiguous
+ *   grad_img : B x C x Hi x Wi contiguous, ACCUMULATED INTO with fp32 atomics -- the caller
+ *              zero-fills it first, exactly as the reference's wrapper does (resample2d.py:31)
+ *   grad_flow: B x 2 x H x W contiguous, fully written */
+int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
+                            const float *grad_out, float *grad_img, float *grad_flow,
+                            int B, int C, int Hi, int Wi, int H, int W,
+                            int kernel_size, int bilinear, void *stream);
+
+/* Replaces channelnorm_kernel_forward (channelnorm_kernel.cuh:5-8; kernel
+ * channelnorm_kernel.cu:18-60).  in : B x C x H x W contiguous, out : B x 1 x H x W contiguous.
+ * norm_deg is accepted and ignored by the reference kernels (always L2); not part of this ABI. */
+int fn2_channelnorm_forward(const void *in, void *out, int dtype, int B, int C, int H, int W, void *stream);
+
+/* Replaces channelnorm_kernel_backward (channelnorm_kernel.cuh:10-16; kernel
+ * channelnorm_kernel.cu:63-96).  grad_out is B x 1 x H x W with element strides
+ * gout_strides[4] (NULL = contiguous): the reference ignores gradOutput's strides (:92) and
+ * therefore mis-reads the non-contiguous slice autograd hands it (last bullet);
+ * this entry point honours them. */
+int fn2_channelnorm_backward(const void *in, const void *out, const void *grad_out, const int64_t *gout_strides,
+                             void *grad_in, int dtype, int B, int C, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWNET2_HIP_H */

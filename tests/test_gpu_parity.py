@@ -1,0 +1,341 @@
+"""GPU parity: the gfx950 HIP kernels, reached through the reference-named pybind modules and the
+C ABI, against the CPU oracle on identical seeded inputs and against the committed golden vectors
+(reference kernels under the SIMT shim).
+
+Tolerance: BASELINE.json's north star states <= 1e-4 fp32 max-abs.  TOL below is that bound; most
+paths are far tighter (channelnorm and the resample2d gathers restate the reference's operation
+order and are checked at 1e-6; the atomically-scattered resample grad_img and the MFMA correlation,
+whose summation order differs from the reference's 32-lane tree, get the full budget)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, max_abs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU (run through gpurun)"
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_native_library_is_loaded(dev):
+    import fn2_capi
+    import correlation_cuda  # noqa: F401
+    fn2_capi.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libflownet2_hip.so" in maps
+    hips = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
+    assert len(hips) == 1, f"more than one HIP runtime mapped: {hips}"
+
+
+# ------------------------------------------------------------------ channelnorm
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 2, 7, 9), (3, 5, 6, 10), (8, 3, 384, 512), (8, 2, 384, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.float16])
+def test_channelnorm(dev, oracle, shape, dtype):
+    import channelnorm_cuda
+    if dtype != torch.float32 and shape[-1] == 512:
+        pytest.skip("full size checked in fp32")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    x[0, :, 0, 0] = 0
+    x = x.to(dtype)
+    xd = x.to(dev)
+    out = torch.zeros((shape[0], 1) + shape[2:], dtype=dtype, device=dev)
+    assert channelnorm_cuda.forward(xd, out, 2) == 1
+    go = torch.randn(out.shape, generator=g, dtype=torch.float32).to(dtype)
+    gin = torch.zeros_like(xd)
+    assert channelnorm_cuda.backward(xd, out, go.to(dev), gin, 2) == 1
+    if dtype == torch.float16:
+        # oracle has no half type: compare against the fp32 oracle on the half-rounded inputs
+        xo = x.float().numpy()
+        ref = oracle.chnorm_fwd(xo)
+        assert max_abs(out.float().cpu().numpy(), ref) <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+        refg = oracle.chnorm_bwd(xo, out.float().cpu().numpy(), go.float().numpy())
+        assert max_abs(gin.float().cpu().numpy(), refg) <= 4e-3 * max(1.0, float(np.abs(refg).max()))
+        return
+    xo = x.numpy()
+    ref = oracle.chnorm_fwd(xo)
+    assert max_abs(out.cpu().numpy(), ref) <= 1e-6
+    refg = oracle.chnorm_bwd(xo, ref, go.numpy())
+    assert max_abs(gin.cpu().numpy(), refg) <= 1e-6
+    assert torch.isfinite(gin).all()
+
+
+def test_channelnorm_strided_grad_output(dev, oracle):
+    """gradOutput arrives as a channel slice of a cat gradient: strides are honoured."""
+    import channelnorm_cuda
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 3, 16, 20, generator=g)
+    big = torch.randn(4, 9, 16, 20, generator=g)
+    xd = x.to(dev)
+    out = torch.zeros(4, 1, 16, 20, device=dev)
+    channelnorm_cuda.forward(xd, out, 2)
+    go_view = big.to(dev)[:, 4:5]
+    assert not go_view.is_contiguous()
+    gin = torch.zeros_like(xd)
+    channelnorm_cuda.backward(xd, out, go_view, gin, 2)
+    ref = oracle.chnorm_bwd(x.numpy(), out.cpu().numpy(), big[:, 4:5].contiguous().numpy())
+    assert max_abs(gin.cpu().numpy(), ref) <= 1e-6
+    # odd sizes take the scalar kernel, with fully general strides
+    x2 = torch.randn(2, 2, 5, 7, generator=g)
+    o2 = torch.zeros(2, 1, 5, 7, device=dev)
+    channelnorm_cuda.forward(x2.to(dev), o2, 2)
+    gbig = torch.randn(2, 1, 7, 5, generator=g)
+    gv = gbig.to(dev).permute(0, 1, 3, 2)
+    g2 = torch.zeros(2, 2, 5, 7, device=dev)
+    channelnorm_cuda.backward(x2.to(dev), o2, gv, g2, 2)
+    ref2 = oracle.chnorm_bwd(x2.numpy(), o2.cpu().numpy(), gbig.permute(0, 1, 3, 2).contiguous().numpy())
+    assert max_abs(g2.cpu().numpy(), ref2) <= 1e-6
+
+
+# ------------------------------------------------------------------ resample2d
+def _flow(g, shape, scale):
+    f = torch.randn(shape, generator=g) * scale
+    flat = f.view(-1)
+    idx = torch.randint(0, flat.numel(), (max(1, flat.numel() // 100),), generator=g)
+    flat[idx] *= 20.0   # 1 % far out of range: forces border clamps
+    return f
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24, 16, 24), (1, 2, 9, 11, 9, 11), (1, 3, 10, 14, 8, 12), (8, 3, 384, 512, 384, 512)])
+@pytest.mark.parametrize("bilinear", [True, False])
+def test_resample2d(dev, oracle, shape, bilinear):
+    import resample2d_cuda
+    B, C, Hi, Wi, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(B, C, Hi, Wi, generator=g) - 0.5
+    flow = _flow(g, (B, 2, H, W), 4.0)
+    gout = torch.randn(B, C, H, W, generator=g)
+    out = torch.zeros(B, C, H, W, device=dev)
+    assert resample2d_cuda.forward(img.to(dev), flow.to(dev), out, 1, bilinear) == 1
+    ref = oracle.resample_fwd(img.numpy(), flow.numpy(), 1, bilinear)
+    assert max_abs(out.cpu().numpy(), ref) <= 1e-6
+    gimg = torch.zeros(B, C, Hi, Wi, device=dev)
+    gflow = torch.zeros(B, 2, H, W, device=dev)
+    assert resample2d_cuda.backward(img.to(dev), flow.to(dev), gout.to(dev), gimg, gflow, 1, bilinear) == 1
+    rimg, rflow = oracle.resample_bwd(img.numpy(), flow.numpy(), gout.numpy(), 1, bilinear)
+    assert max_abs(gflow.cpu().numpy(), rflow) <= 1e-6
+    assert max_abs(gimg.cpu().numpy(), rimg) <= TOL     # fp32 atomics: order differs from the oracle's
+
+
+def test_resample2d_strided_image_and_accumulate(dev, oracle):
+    """The kernel reads input1 through its strides (models.py:133 passes x[:, 3:, :, :]) and the
+    backward ACCUMULATES into grad_input1 (caller zero-fills, resample2d.py:31)."""
+    import resample2d_cuda
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 6, 12, 16, generator=g)
+    flow = _flow(g, (2, 2, 12, 16), 2.0)
+    xd = x.to(dev)
+    view = xd[:, 3:]
+    assert not view.is_contiguous()
+    out = torch.zeros(2, 3, 12, 16, device=dev)
+    resample2d_cuda.forward(view, flow.to(dev), out, 1, True)
+    ref = oracle.resample_fwd(x[:, 3:].contiguous().numpy(), flow.numpy())
+    assert max_abs(out.cpu().numpy(), ref) <= 1e-6
+    gout = torch.randn(2, 3, 12, 16, generator=g)
+    gimg = torch.ones(2, 3, 12, 16, device=dev)
+    gflow = torch.zeros(2, 2, 12, 16, device=dev)
+    resample2d_cuda.backward(view, flow.to(dev), gout.to(dev), gimg, gflow, 1, True)
+    rimg, rflow = oracle.resample_bwd(x[:, 3:].contiguous().numpy(), flow.numpy(), gout.numpy())
+    assert max_abs(gimg.cpu().numpy() - 1.0, rimg) <= TOL
+    assert max_abs(gflow.cpu().numpy(), rflow) <= 1e-6
+
+
+def test_resample2d_rejects_non_float(dev):
+    import resample2d_cuda
+    a = torch.zeros(1, 3, 8, 8, device=dev, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="float32"):
+        resample2d_cuda.forward(a, torch.zeros(1, 2, 8, 8, device=dev, dtype=torch.float64), a.clone(), 1, True)
+
+
+# ------------------------------------------------------------------ correlation
+def _corr_both(dev, in1, in2, gout, params):
+    import correlation_cuda
+    a, b = to_dev(in1, dev), to_dev(in2, dev)
+    e = lambda: a.new_empty(0)  # noqa: E731
+    out = e()
+    assert correlation_cuda.forward(a, b, e(), e(), out, *params, 1) == 1
+    res = [out]
+    if gout is not None:
+        g1, g2 = e(), e()
+        assert correlation_cuda.backward(a, b, e(), e(), to_dev(gout, dev), g1, g2, *params, 1) == 1
+        res += [g1, g2]
+    torch.cuda.synchronize()
+    return [r.cpu().numpy() for r in res]
+
+
+@pytest.mark.parametrize("path", golden_files("corr"), ids=os.path.basename)
+def test_correlation_golden(dev, path):
+    g = np.load(path)
+    params = tuple(int(v) for v in g["params"])
+    has_bwd = "g1" in g.files
+    res = _corr_both(dev, g["in1"], g["in2"], g["gout"] if has_bwd else None, params)
+    assert res[0].shape == g["out"].shape
+    assert max_abs(res[0], g["out"]) <= TOL
+    if has_bwd:
+        assert max_abs(res[1], g["g1"]) <= TOL and max_abs(res[2], g["g2"]) <= TOL
+
+
+MFMA_CASES = [  # B, C, H, W, md  (k=1, s1=1, s2=2, pad=md)
+    (1, 32, 6, 8, 20), (2, 16, 8, 8, 20), (1, 64, 16, 24, 20), (1, 16, 10, 40, 20), (1, 16, 8, 130, 20),
+    (1, 32, 12, 16, 4), (2, 16, 10, 12, 6), (1, 16, 6, 6, 2), (1, 48, 14, 18, 10), (1, 16, 20, 72, 14),
+    (1, 16, 8, 8, 21),
+]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES)
+def test_correlation_mfma_vs_oracle(dev, oracle, case):
+    import fn2_capi
+    B, C, H, W, md = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W + md)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    ad, bd = to_dev(a, dev), to_dev(b, dev)
+    out = torch.full((B, (2 * (md // 2) + 1) ** 2, H, W), float("nan"), device=dev)   # every element must be written
+    fn2_capi.correlation_forward(ad, bd, md, 1, md, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F32, out=out)
+    direct = fn2_capi.correlation_forward(ad, bd, md, 1, md, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    ref = oracle.corr_fwd(a, b, md, 1, md, 1, 2)
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all(), "MFMA kernel left output elements unwritten"
+    assert max_abs(o, ref) <= TOL
+    assert max_abs(direct.cpu().numpy(), ref) <= TOL
+    assert max_abs(o, ref) <= 2e-6, "fp32 MFMA chain should agree with the fp32 oracle to rounding"
+
+
+@pytest.mark.parametrize("dist", ["normal", "leaky"])
+def test_correlation_full_size_vs_oracle(dev, oracle, dist):
+    """BASELINE.json configs[1]: fwd+bwd on 8x256x48x64 fp32, <= 1e-4 max-abs (oracle on 2 of the
+    8 batch items to keep CPU time bounded; items are independent)."""
+    g = torch.Generator().manual_seed(0)
+    shape = (8, 256, 48, 64)
+    a = torch.randn(shape, generator=g)
+    b = torch.randn(shape, generator=g)
+    if dist == "leaky":   # mimic conv3 activations (LeakyReLU 0.1)
+        a, b = torch.nn.functional.leaky_relu(a, 0.1), torch.nn.functional.leaky_relu(b, 0.1)
+    go = torch.randn((8, 441, 48, 64), generator=torch.Generator().manual_seed(1))
+    params = (20, 1, 20, 1, 2)
+    out, g1, g2 = _corr_both(dev, a.numpy(), b.numpy(), go.numpy(), params)
+    for n in (0, 7):
+        sl = slice(n, n + 1)
+        ref = oracle.corr_fwd(a[sl].numpy(), b[sl].numpy(), *params)
+        assert max_abs(out[sl], ref) <= TOL
+        r1, r2 = oracle.corr_bwd(a[sl].numpy(), b[sl].numpy(), go[sl].numpy(), *params)
+        assert max_abs(g1[sl], r1) <= TOL and max_abs(g2[sl], r2) <= TOL
+
+
+def test_correlation_full_size_properties(dev):
+    """Size-independent properties at the BASELINE size: the all-ones pattern counts padding,
+    the output is linear in in2, and batch items are independent."""
+    import fn2_capi
+    ones = torch.ones(8, 256, 48, 64, device=dev)
+    out = fn2_capi.correlation_forward(ones, ones, 20, 1, 20, 1, 2)
+    ys = torch.arange(48, device=dev).view(48, 1)
+    xs = torch.arange(64, device=dev).view(1, 64)
+    for tj, ti in [(0, 0), (10, 10), (20, 3), (7, 19)]:
+        dy, dx = 2 * (tj - 10), 2 * (ti - 10)
+        exp = ((ys + dy >= 0) & (ys + dy < 48) & (xs + dx >= 0) & (xs + dx < 64)).float()
+        assert torch.equal(out[3, tj * 21 + ti], exp), (tj, ti)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(8, 256, 48, 64, generator=g).to(dev)
+    b1 = torch.randn(8, 256, 48, 64, generator=g).to(dev)
+    b2 = torch.randn(8, 256, 48, 64, generator=g).to(dev)
+    lhs = fn2_capi.correlation_forward(a, b1 + b2, 20, 1, 20, 1, 2)
+    rhs = fn2_capi.correlation_forward(a, b1, 20, 1, 20, 1, 2) + fn2_capi.correlation_forward(a, b2, 20, 1, 20, 1, 2)
+    assert float((lhs - rhs).abs().max()) <= 2e-6
+    solo = fn2_capi.correlation_forward(a[5:6].contiguous(), b1[5:6].contiguous(), 20, 1, 20, 1, 2)
+    full = fn2_capi.correlation_forward(a, b1, 20, 1, 20, 1, 2)
+    assert torch.equal(solo[0], full[5])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16])
+def test_correlation_other_dtypes(dev, oracle, dtype):
+    import correlation_cuda
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((2, 24, 10, 12)).astype(np.float32)
+    b = rng.standard_normal((2, 24, 10, 12)).astype(np.float32)
+    ad, bd = torch.from_numpy(a).to(dev, dtype), torch.from_numpy(b).to(dev, dtype)
+    out = ad.new_empty(0)
+    correlation_cuda.forward(ad, bd, ad.new_empty(0), ad.new_empty(0), out, 4, 1, 4, 1, 2, 1)
+    assert out.dtype == dtype and tuple(out.shape) == (2, 25, 10, 12)
+    a_r, b_r = ad.double().cpu().numpy(), bd.double().cpu().numpy()
+    ref = oracle.corr_fwd(a_r, b_r, 4, 1, 4, 1, 2)
+    tol = TOL if dtype == torch.float64 else 3e-3
+    assert max_abs(out.double().cpu().numpy(), ref) <= tol
+    go = torch.from_numpy(rng.standard_normal(ref.shape).astype(np.float32)).to(dev, dtype)
+    g1, g2 = ad.new_empty(0), ad.new_empty(0)
+    correlation_cuda.backward(ad, bd, ad.new_empty(0), ad.new_empty(0), go, g1, g2, 4, 1, 4, 1, 2, 1)
+    r1, r2 = oracle.corr_bwd(a_r, b_r, go.double().cpu().numpy(), 4, 1, 4, 1, 2)
+    assert max_abs(g1.double().cpu().numpy(), r1) <= tol * 4 and max_abs(g2.double().cpu().numpy(), r2) <= tol * 4
+
+
+def test_correlation_kernel3_and_stride1(dev, oracle):
+    """Parameter-general path: kernel_size 3 where the reference is defined (md - dr*s2 >= 1) and
+    stride1 = 2 forward."""
+    import fn2_capi
+    rng = np.random.default_rng(12)
+    a = rng.standard_normal((1, 8, 12, 12)).astype(np.float32)
+    b = rng.standard_normal((1, 8, 12, 12)).astype(np.float32)
+    for params in [(5, 3, 5, 1, 2), (4, 1, 4, 2, 2), (6, 3, 5, 2, 3)]:
+        out = fn2_capi.correlation_forward(to_dev(a, dev), to_dev(b, dev), *params)
+        assert max_abs(out.cpu().numpy(), oracle.corr_fwd(a, b, *params)) <= TOL
+    out = fn2_capi.correlation_forward(to_dev(a, dev), to_dev(b, dev), 5, 3, 5, 1, 2)
+    go = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    g1, g2 = fn2_capi.correlation_backward(to_dev(a, dev), to_dev(b, dev), to_dev(go, dev), 5, 3, 5, 1, 2)
+    r1, r2 = oracle.corr_bwd(a, b, go, 5, 3, 5, 1, 2)
+    assert max_abs(g1.cpu().numpy(), r1) <= TOL and max_abs(g2.cpu().numpy(), r2) <= TOL
+
+
+# ------------------------------------------------------------------ autograd wrappers (reference API)
+def test_wrappers_autograd(dev, oracle):
+    from networks.channelnorm_package.channelnorm import ChannelNorm
+    from networks.correlation_package.correlation import Correlation
+    from networks.resample2d_package.resample2d import Resample2d
+    g = torch.Generator().manual_seed(13)
+    a = torch.randn(2, 32, 12, 16, generator=g)
+    b = torch.randn(2, 32, 12, 16, generator=g)
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    corr = Correlation(pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2, corr_multiply=1)
+    out = corr(ad, bd)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(dev))
+    r1, r2 = oracle.corr_bwd(a.numpy(), b.numpy(), go.numpy(), 20, 1, 20, 1, 2)
+    assert max_abs(out.detach().cpu().numpy(), oracle.corr_fwd(a.numpy(), b.numpy(), 20, 1, 20, 1, 2)) <= TOL
+    assert max_abs(ad.grad.cpu().numpy(), r1) <= TOL and max_abs(bd.grad.cpu().numpy(), r2) <= TOL
+
+    # the FlowNet2 warp block (models.py:133-138): resample -> diff -> channelnorm -> cat
+    x = torch.randn(2, 6, 16, 24, generator=g)
+    flow = torch.randn(2, 2, 16, 24, generator=g) * 3
+    xd, fd = x.to(dev).requires_grad_(True), flow.to(dev).requires_grad_(True)
+    warped = Resample2d()(xd[:, 3:, :, :], fd)
+    diff = xd[:, :3, :, :] - warped
+    norm = ChannelNorm()(diff.contiguous())
+    cat = torch.cat((xd, warped, fd / 20.0, norm), dim=1)
+    w = torch.randn(cat.shape, generator=g).to(dev)
+    (cat * w).sum().backward()
+    # CPU restatement of the same graph with the oracle's explicit backward passes
+    wn = w.cpu().numpy()
+    warped_o = oracle.resample_fwd(x[:, 3:].contiguous().numpy(), flow.numpy())
+    diff_o = x[:, :3].numpy() - warped_o
+    norm_o = oracle.chnorm_fwd(diff_o)
+    assert max_abs(norm.detach().cpu().numpy(), norm_o) <= TOL
+    g_norm = wn[:, 11:12]
+    g_diff = oracle.chnorm_bwd(diff_o, norm_o, np.ascontiguousarray(g_norm))
+    g_warp = wn[:, 6:9] - g_diff
+    gimg_o, gflow_o = oracle.resample_bwd(x[:, 3:].contiguous().numpy(), flow.numpy(), np.ascontiguousarray(g_warp))
+    gx = wn[:, :6].copy()
+    gx[:, :3] += g_diff
+    gx[:, 3:] += gimg_o
+    gf = wn[:, 9:11] / 20.0 + gflow_o
+    assert max_abs(xd.grad.cpu().numpy(), gx) <= TOL
+    assert max_abs(fd.grad.cpu().numpy(), gf) <= TOL
