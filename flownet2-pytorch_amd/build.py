@@ -61,7 +61,7 @@ def build_modules(force=False):
     tinc = [os.path.join(tdir, "include"), os.path.join(tdir, "include", "torch", "csrc", "api", "include")]
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
-    outs = []
+    outs, jobs = [], []
     for m in MODULES:
         src = os.path.join(CSRC, "binding", m + ".cpp")
         out = os.path.join(HERE, m + ext)
@@ -75,8 +75,13 @@ def build_modules(force=False):
             cmd += [src, "-o", out, "-L" + os.path.join(tdir, "lib"), "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu",
                     "-ltorch_hip", "-ltorch_python", "-L" + LIBDIR, "-lflownet2_hip",
                     "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath," + os.path.join(tdir, "lib")]
-            _run(cmd)
+            jobs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         outs.append(out)
+    for cmd, pr in jobs:  # the three translation units compile concurrently
+        log, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(" ".join(cmd) + "\n" + log)
+            raise RuntimeError("build step failed: g++")
     return outs
 
 

@@ -4,8 +4,8 @@
 // forward to the C ABI in include/flownet2_hip.h on the caller's current HIP stream.
 #pragma once
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 
 #include "flownet2_hip.h"
 
@@ -43,9 +43,11 @@ inline void check_rc(int rc, const char *op)
     TORCH_CHECK(rc == FN2_OK, op, ": HIP call failed: ", fn2_strerror(rc), " (code ", rc, ")");
 }
 
+// PyTorch-ROCm presents HIP devices as device type "cuda"; the masquerading accessor is the one
+// that matches the tensors' device type (the plain c10::hip guard/stream classes expect type "hip").
 inline void *current_stream(const at::Tensor &t)
 {
-    return static_cast<void *>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+    return static_cast<void *>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream());
 }
 
 } // namespace fn2b

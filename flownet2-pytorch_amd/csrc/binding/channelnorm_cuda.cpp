@@ -17,7 +17,7 @@ int channelnorm_forward_hip(at::Tensor &input1, at::Tensor &output, int norm_deg
     TORCH_CHECK(output.size(0) == B && output.size(1) == 1 && output.size(2) == H && output.size(3) == W, op,
                 ": output has shape ", output.sizes(), ", expected [", B, ", 1, ", H, ", ", W, "]");
     TORCH_CHECK(output.is_contiguous(), op, ": output must be contiguous");
-    c10::hip::HIPGuard guard(input1.device());
+    c10::DeviceGuard guard(input1.device());
     at::Tensor a = input1.contiguous();
     check_rc(fn2_channelnorm_forward(a.data_ptr(), output.data_ptr(), dt, B, C, H, W, current_stream(input1)), op);
     return 1;
@@ -43,7 +43,7 @@ int channelnorm_backward_hip(at::Tensor &input1, at::Tensor &output, at::Tensor 
                 output.sizes());
     TORCH_CHECK(gradInput1.sizes() == input1.sizes() && gradInput1.is_contiguous(), op,
                 ": gradInput1 must be contiguous and shaped like input1");
-    c10::hip::HIPGuard guard(input1.device());
+    c10::DeviceGuard guard(input1.device());
     at::Tensor a = input1.contiguous(), o = output.contiguous();
     int64_t gs[4];
     for (int i = 0; i < 4; ++i) gs[i] = gradOutput.stride(i);

@@ -24,7 +24,7 @@ int correlation_forward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &
     int nOut = 0, oH = 0, oW = 0;
     check_rc(fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut, &oH,
                                           &oW), op);
-    c10::hip::HIPGuard guard(input1.device());
+    c10::DeviceGuard guard(input1.device());
     at::Tensor a = input1.contiguous(), b = input2.contiguous();
     output.resize_({B, nOut, oH, oW}); // correlation_cuda.cc:38; fully written by the kernel, no fill_(0)
     TORCH_CHECK(output.is_contiguous(), op, ": output must be contiguous");
@@ -54,7 +54,7 @@ int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor 
     TORCH_CHECK(gradOutput.dim() == 4 && gradOutput.size(0) == B && gradOutput.size(1) == nOut &&
                     gradOutput.size(2) == oH && gradOutput.size(3) == oW,
                 op, ": gradOutput has shape ", gradOutput.sizes(), ", expected [", B, ", ", nOut, ", ", oH, ", ", oW, "]");
-    c10::hip::HIPGuard guard(input1.device());
+    c10::DeviceGuard guard(input1.device());
     at::Tensor a = input1.contiguous(), b = input2.contiguous();
     at::Tensor go = gradOutput.contiguous(); // the reference assumes contiguity without checking (SURVEY.md b)
     gradInput1.resize_({B, C, H, W});        // correlation_cuda.cc:108-109; fully written, no fill_(0)

@@ -26,7 +26,7 @@ int resample2d_forward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &o
     TORCH_CHECK(input1.size(0) == B && input1.size(1) == C, op, ": input1 ", input1.sizes(), " does not match output ",
                 output.sizes());
     TORCH_CHECK(output.is_contiguous(), op, ": output must be contiguous");
-    c10::hip::HIPGuard guard(input1.device());
+    c10::DeviceGuard guard(input1.device());
     at::Tensor flow = input2.contiguous();
     int64_t is[4];
     strides4(input1, is); // honoured by the kernel, like the reference's DIM3_INDEX
@@ -58,7 +58,7 @@ int resample2d_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &
                 ": gradInput1 must be contiguous and shaped like input1");
     TORCH_CHECK(gradInput2.sizes() == input2.sizes() && gradInput2.is_contiguous(), op,
                 ": gradInput2 must be contiguous and shaped like input2");
-    c10::hip::HIPGuard guard(input1.device());
+    c10::DeviceGuard guard(input1.device());
     at::Tensor flow = input2.contiguous(), go = gradOutput.contiguous();
     int64_t is[4];
     strides4(input1, is);
