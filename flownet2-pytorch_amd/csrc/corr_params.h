@@ -16,6 +16,10 @@ int corr_backward_direct(const void *in1, const void *in2, const void *gout, voi
                          const CorrP &p, hipStream_t s);
 bool corr_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
-                          hipStream_t s);
+                          int tune, hipStream_t s);
+
+bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
+int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,
+                           int B, int C, int H, int W, int md, int tune, hipStream_t s);
 
 } // namespace fn2

@@ -1,0 +1,82 @@
+"""Micro-benchmark of correlation-forward instantiations through the C ABI (fn2_correlation_forward_ex).
+algo 2 = shipped MFMA kernel; 100 + 8*cfg + var = profiling instantiations (correlation_mfma.hip).
+Usage: python scripts/corr_micro.py [--algos 2,100,101,...] [--iters 30] [--check]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
+import torch  # noqa: E402
+import fn2_capi  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--algos", default="2")
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--check", action="store_true")
+ap.add_argument("--shape", default="8,256,48,64")
+ap.add_argument("--md", type=int, default=20)
+ap.add_argument("--bwd", default="")
+a = ap.parse_args()
+B, C, H, W = (int(v) for v in a.shape.split(","))
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+in1 = torch.randn(B, C, H, W, generator=g).to(dev)
+in2 = torch.randn(B, C, H, W, generator=g).to(dev)
+D = 2 * (a.md // 2) + 1
+out = torch.empty(B, D * D, H, W, device=dev)
+ref = None
+res = {}
+for algo in (int(v) for v in a.algos.split(",")):
+    try:
+        for _ in range(3):
+            fn2_capi.correlation_forward(in1, in2, a.md, 1, a.md, 1, 2, algo=algo, out=out)
+    except RuntimeError as e:
+        print(algo, "ERR", e)
+        continue
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(a.iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn2_capi.correlation_forward(in1, in2, a.md, 1, a.md, 1, 2, algo=algo, out=out)
+        e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
+    r = {"median_us": round(ts[len(ts) // 2], 2), "min_us": round(ts[0], 2)}
+    if a.check and (algo == 2 or (algo >= 100 and (algo - 100) % 8 == 0)):
+        if ref is None:
+            ref = fn2_capi.correlation_forward(in1, in2, a.md, 1, a.md, 1, 2, algo=1)
+        r["max_abs_vs_direct"] = float((out - ref).abs().max())
+    res[algo] = r
+    print(algo, r, flush=True)
+if a.bwd:
+    gout = torch.randn(B, D * D, H, W, generator=g).to(dev)
+    refb = None
+    for algo in (int(v) for v in a.bwd.split(",")):
+        try:
+            for _ in range(2):
+                g1, g2 = fn2_capi.correlation_backward(in1, in2, gout, a.md, 1, a.md, 1, 2, algo=algo)
+        except RuntimeError as e:
+            print("bwd", algo, "ERR", e)
+            continue
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(a.iters):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn2_capi.correlation_backward(in1, in2, gout, a.md, 1, a.md, 1, 2, algo=algo)
+            e.record()
+            evs.append((s, e))
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
+        r = {"median_us": round(ts[len(ts) // 2], 2), "min_us": round(ts[0], 2)}
+        if a.check:
+            if refb is None:
+                refb = fn2_capi.correlation_backward(in1, in2, gout, a.md, 1, a.md, 1, 2, algo=1)
+            r["max_abs_vs_direct"] = [float((g1 - refb[0]).abs().max()), float((g2 - refb[1]).abs().max())]
+        res["bwd%d" % algo] = r
+        print("bwd", algo, r, flush=True)
+print(json.dumps(res))

@@ -213,6 +213,31 @@ def test_correlation_mfma_vs_oracle(dev, oracle, case):
     assert max_abs(o, ref) <= 2e-6, "fp32 MFMA chain should agree with the fp32 oracle to rounding"
 
 
+BWD_CASES = [  # B, C, H, W, md  (k=1, s1=1, s2=2, pad=md); C % 32 == 0
+    (1, 32, 6, 8, 20), (2, 64, 8, 8, 20), (1, 64, 16, 24, 20), (1, 32, 10, 40, 20), (1, 32, 8, 130, 20),
+    (1, 32, 12, 16, 4), (2, 64, 10, 12, 6), (1, 32, 6, 6, 2), (1, 96, 14, 18, 10), (1, 32, 20, 72, 14), (1, 128, 8, 8, 21),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_correlation_mfma_backward_vs_oracle(dev, oracle, case):
+    import fn2_capi
+    B, C, H, W, md = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W + md + 1)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    D = 2 * (md // 2) + 1
+    go = rng.standard_normal((B, D * D, H, W)).astype(np.float32)
+    ad, bd, gd = to_dev(a, dev), to_dev(b, dev), to_dev(go, dev)
+    r1, r2 = oracle.corr_bwd(a, b, go, md, 1, md, 1, 2)
+    for algo in (fn2_capi.FN2_CORR_MFMA_F32, 101, fn2_capi.FN2_CORR_DIRECT):   # 101: 32-channel groups
+        g1, g2 = fn2_capi.correlation_backward(ad, bd, gd, md, 1, md, 1, 2, algo=algo)
+        e1, e2 = max_abs(g1.cpu().numpy(), r1), max_abs(g2.cpu().numpy(), r2)
+        assert e1 <= TOL and e2 <= TOL, (algo, e1, e2)
+        scale = max(1.0, float(np.abs(r1).max()))
+        assert e1 <= 5e-6 * scale and e2 <= 5e-6 * scale, (algo, e1, e2)   # fp32 sums in a different order only
+
+
 @pytest.mark.parametrize("dist", ["normal", "leaky"])
 def test_correlation_full_size_vs_oracle(dev, oracle, dist):
     """BASELINE.json configs[1]: fwd+bwd on 8x256x48x64 fp32, <= 1e-4 max-abs (oracle on 2 of the
