@@ -189,6 +189,117 @@ __global__ __launch_bounds__(256) void resample_bwd_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------- backward, LDS-privatised scatter
+// Device-scope fp32 atomics to scattered addresses leave the XCD (the per-XCD L2s are not coherent)
+// and run at a few tens of G atomics/s.  Here a workgroup owns a TH x TW tile of SOURCE pixels and
+// accumulates their four-corner contributions into an LDS window covering the tile +- R pixels with
+// LDS atomics; only targets outside the window (|flow| > R) go to global memory one by one.  The
+// window is then flushed as contiguous rows (64 lanes = 256 B of consecutive addresses per atomic
+// instruction, exact zeros skipped), because the windows of neighbouring tiles overlap.
+// grad_flow is formed exactly as in resample_bwd_kernel (same operation order).
+template <int TH, int TW, int R, int CC>
+__global__ __launch_bounds__(512) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
+                                                         const float *__restrict__ flow,
+                                                         const float *__restrict__ gout,
+                                                         float *__restrict__ gimg, float *__restrict__ gflow,
+                                                         int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y)
+{
+    constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1;   // +1: rows start on different banks
+    constexpr int NT = 512;                                         // threads per workgroup
+    constexpr int PPT = TH * TW / NT;                               // source pixels per thread
+    __shared__ float win[CC * WH * WWP];
+
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int X0 = tx * TW, Y0 = ty * TH;
+    const int wx0 = X0 - R, wy0 = Y0 - R;
+    const long HW = (long)H * W, HWi = (long)Hi * Wi;
+
+    float out_dx[PPT], out_dy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) out_dx[k] = out_dy[k] = 0.0f;
+
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        const int nc = min(CC, C - c0);
+        for (int i = tid; i < CC * WH * WWP; i += NT) win[i] = 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            if (x >= W || y >= H) continue;
+            const long p = (long)y * W + x;
+            const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+            const float xf = (float)x + dx, yf = (float)y + dy;
+            const float fx = floorf(xf), fy = floorf(yf);
+            const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
+            const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);   // (:105-106)
+            const int sxL = clampi(ixL, 0, Wi - 1), sxR = clampi(ixR, 0, Wi - 1);          // (:108-114)
+            const int syT = clampi(iyT, 0, Hi - 1), syB = clampi(iyB, 0, Hi - 1);
+            const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta);
+            const float s10 = (1 - alpha) * beta, s11 = alpha * beta;
+            // all four corners lie in [sxL, sxR] x [syT, syB]: one window test per pixel
+            const int lxL = sxL - wx0, lxR = sxR - wx0, lyT = syT - wy0, lyB = syB - wy0;
+            const bool inwin = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            const int gxL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), gxR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
+            const int gyT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), gyB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
+            const float gam_y = 1 - (xf - fx), gam_x = 1 - (yf - fy);
+            for (int cc = 0; cc < nc; ++cc) {
+                const int ch = c0 + cc;
+                const float go = gout[((long)b * C + ch) * HW + p];
+                if (inwin) {
+                    float *Wc = win + cc * (WH * WWP);
+                    atomicAdd(Wc + lyT * WWP + lxL, s00 * go);   // ds_add_f32
+                    atomicAdd(Wc + lyT * WWP + lxR, s01 * go);
+                    atomicAdd(Wc + lyB * WWP + lxL, s10 * go);
+                    atomicAdd(Wc + lyB * WWP + lxR, s11 * go);
+                } else {
+                    float *G = gimg + ((long)b * C + ch) * HWi;
+                    unsafeAtomicAdd(G + (long)syT * Wi + sxL, s00 * go);
+                    unsafeAtomicAdd(G + (long)syT * Wi + sxR, s01 * go);
+                    unsafeAtomicAdd(G + (long)syB * Wi + sxL, s10 * go);
+                    unsafeAtomicAdd(G + (long)syB * Wi + sxR, s11 * go);
+                }
+                const float *I = img + (long)b * is.b + (long)ch * is.c;
+                const float iTL = I[gyT * is.h + gxL * is.w], iTR = I[gyT * is.h + gxR * is.w];
+                const float iBL = I[gyB * is.h + gxL * is.w], iBR = I[gyB * is.h + gxR * is.w];
+                out_dy[k] = out_dy[k] + (gam_y * go) * iBL;       // (:172-177)
+                out_dy[k] = out_dy[k] - (gam_y * go) * iTL;
+                out_dy[k] = out_dy[k] + ((1 - gam_y) * go) * iBR;
+                out_dy[k] = out_dy[k] - ((1 - gam_y) * go) * iTR;
+                out_dx[k] = out_dx[k] + (gam_x * go) * iTR;       // (:185-190)
+                out_dx[k] = out_dx[k] - (gam_x * go) * iTL;
+                out_dx[k] = out_dx[k] + ((1 - gam_x) * go) * iBR;
+                out_dx[k] = out_dx[k] - ((1 - gam_x) * go) * iBL;
+            }
+        }
+        __syncthreads();
+        // flush: window rows are contiguous in grad_img
+        for (int i = tid; i < nc * WH * WW; i += NT) {
+            const int lx = i % WW;
+            const int r = i / WW;
+            const int ly = r % WH, cc = r / WH;
+            const int gx = wx0 + lx, gy = wy0 + ly;
+            const float v = win[cc * (WH * WWP) + ly * WWP + lx];
+            if (v != 0.0f && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi)
+                unsafeAtomicAdd(gimg + ((long)b * C + c0 + cc) * HWi + (long)gy * Wi + gx, v);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        if (x >= W || y >= H) continue;
+        const long p = (long)y * W + x;
+        gflow[(long)b * 2 * HW + p] = out_dx[k];
+        gflow[(long)b * 2 * HW + HW + p] = out_dy[k];
+    }
+}
+
 static inline unsigned stream_grid(long nthreads)
 {
     long blocks = (nthreads + 255) / 256;
@@ -232,7 +343,8 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
                                        int kernel_size, int bilinear, void *stream)
 {
     using namespace fn2;
-    (void)bilinear; // both reference backward kernels ignore the flag
+    // both reference backward kernels ignore the bilinear flag; bit 8 of it selects the
+    // untiled scatter kernel (profiling / A-B only)
     if (B < 0 || C < 0 || Hi < 1 || Wi < 1 || H < 0 || W < 0) return FN2_EINVAL;
     if (kernel_size != 1) return FN2_EUNSUPPORTED;
     if ((long)B * H * W == 0) return FN2_OK;
@@ -244,7 +356,14 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
     else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long npix = (long)B * H * W;
-    hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out, grad_img,
-                       grad_flow, C, Hi, Wi, H, W, npix);
+    if (H >= 16 && W >= 32 && !(bilinear & 0x100)) {
+        constexpr int TH = 32, TW = 64;
+        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, 16, 3>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(512),
+                           0, s, img, is, flow, grad_out, grad_img, grad_flow, C, Hi, Wi, H, W, tiles_x, tiles_y);
+    } else {
+        hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out,
+                           grad_img, grad_flow, C, Hi, Wi, H, W, npix);
+    }
     return launch_status();
 }
