@@ -33,6 +33,8 @@
 // HBM traffic: in1/in2 tiles are re-read by the NV row-block tasks and by neighbouring row
 // groups, but those re-reads are served by L2 / Infinity Cache (both inputs total 50 MB at the
 // FlowNetC shape); algorithmic bytes are 2 * B*C*H*W*4 read + B*D*D*H*W*4 written.
+#include <type_traits>
+
 #include "corr_params.h"
 
 namespace fn2 {
@@ -57,6 +59,7 @@ struct Args {
     int C, H, W;     // H, W even
     int dr, D, NV;   // displacement radius (lattice), 2dr+1, B blocks per A block per axis
     int NRG, NXT;    // row groups per parity, x tiles
+    unsigned long long *dbg;   // profiling only: s_memtime stamps (VAR bit 8 of the DMA kernel), else null
 };
 
 // Tunables of one instantiation.
@@ -64,7 +67,9 @@ struct Args {
 //   NBUF  1: one operand buffer, two barriers per chunk; 2: double-buffered, one barrier per chunk
 //   EP    epilogue passes (1: all 16 (ai,bi) planes at once = 87 KB of LDS; 2: 8 planes per pass)
 //   WPS   waves per SIMD the register budget is sized for (= workgroups per CU * 2)
-//   VAR   ablation switches for profiling only (0 = the real kernel): 1 no MFMA, 2 no staging, 4 no stores
+//   VAR   ablation switches for profiling only (0 = the real kernel): 1 no MFMA, 2 no staging, 4 no stores,
+//         8 no LDS fragment reads, 16 every chunk re-reads chunk 0 (L2-hot inputs),
+//         32 no global loads, 64 no LDS staging writes
 template <int CK, int NBUF, int EP>
 struct Cfg {
     static constexpr int A_FLOATS = CK * A_CH, B_FLOATS = CK * B_CH, BUF_FLOATS = A_FLOATS + B_FLOATS;
@@ -72,12 +77,82 @@ struct Cfg {
     static constexpr int LDS_FLOATS = (NBUF * BUF_FLOATS > O_FLOATS) ? NBUF * BUF_FLOATS : O_FLOATS;
 };
 
-template <int NV, int CK, int NBUF, int EP, int WPS, int VAR>
+// ---- epilogue shared by the forward kernels: accumulators -> LDS [ai][bi][ti][x] -> coalesced rows
+// D layout of v_mfma_f32_16x16x4_f32: lane l, register r holds D[row = 4*(l>>4) + r][col = l&15];
+// rows are A pixels (ai = row>>2 = l>>4, aj = row&3 = r), columns B pixels (bi = fi>>2, bj = fi&3).
+// The caller guarantees that every wave has finished reading the operand buffers that alias `smem`.
+template <int NV, int EP, int VAR, int NW = 8>
+__device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Args &p, int lane, int wave, int n,
+                                         int py, int rg, int u, int X0, int HL, long HW)
+{
+    // waves 0..7 hold accumulators; any further waves (loader waves of the specialised kernel) only help
+    // with the write-out
+    const bool holds_acc = (NW == 8) || (wave < 8);
+    const int xpar = wave & 1;
+    const int a0 = (wave >> 1) << 1;
+    const int fi = lane & 15, fq = lane >> 4;
+    {
+        float *Os = smem;
+        constexpr int AI_PER_PASS = 4 / EP;
+        constexpr int DUMMY = (16 / EP) * (2 * DR_MAX + 1) * O_RS;   // one spare row: sink for out-of-band entries
+        const int e_ai = fq, e_bi = fi >> 2, e_bj = fi & 3;
+        // acc / nelems as the reference forms it (correlation_cuda_kernel.cu:143); a power-of-two
+        // channel count makes the reciprocal multiply exact, otherwise divide.
+        const float fC = (float)p.C;
+        const bool pow2 = (p.C & (p.C - 1)) == 0;
+        const float rC = 1.0f / fC;
+        const int hx = lane & 31, hr = lane >> 5;   // write-out: lane = (row-in-pair, x pair)
+        const int xg = X0 + 2 * hx;
+#pragma unroll
+        for (int pass = 0; pass < EP; ++pass) {
+            const bool mine = holds_acc && ((EP == 1) || ((e_ai / AI_PER_PASS) == pass));
+            const int plane = ((e_ai % AI_PER_PASS) * 4 + e_bi) * p.D;
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ti = 4 * v + e_bj - r;
+                        const int x = 2 * (4 * (a0 + ab) + r) + xpar;
+                        bool ok = mine;
+                        if (v == 0) ok = ok && (ti >= 0);            // only the first and the last two block columns
+                        if (v >= NV - 2) ok = ok && (ti < p.D);      // can fall outside the displacement band
+                        const int addr = ok ? (plane + ti) * O_RS + x : DUMMY + lane;
+                        if (mine) Os[addr] = acc[ab][v][r];
+                    }
+            __syncthreads();
+            // each wave writes whole planes: rows (plane, ti) for ti = 0..D-1, two rows per instruction,
+            // 8 B per lane -> one 256 B contiguous segment per row
+            for (int pl = wave; pl < 4 * AI_PER_PASS; pl += NW) {
+                const int ai = pass * AI_PER_PASS + (pl >> 2), bi = pl & 3;
+                const int tj = 4 * u + bi - ai;
+                const int IL = 4 * rg + ai;
+                if (tj < 0 || tj >= p.D || IL >= HL) continue; // wave-uniform
+                const int y = 2 * IL + py;
+                float *orow = p.out + (((long)n * p.D * p.D + (long)tj * p.D) * p.H + y) * p.W + xg;
+                const float *srow = Os + (long)pl * p.D * O_RS + 2 * hx;
+                for (int ti0 = 0; ti0 < p.D; ti0 += 2) {
+                    const int ti = ti0 + hr;
+                    if (ti < p.D && xg < p.W && !(VAR & 4)) {
+                        f2 val = *reinterpret_cast<const f2 *>(srow + ti * O_RS);
+                        if (pow2) { val[0] *= rC; val[1] *= rC; }
+                        else { val[0] /= fC; val[1] /= fC; }
+                        *reinterpret_cast<f2 *>(orow + (long)ti * HW) = val;
+                    }
+                }
+            }
+            if (pass + 1 < EP) __syncthreads();
+        }
+    }
+}
+
+template <int NV, int CK, int NBUF, int EP, int WPS, int VAR, bool X4, bool DMAX = false>
 __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
 {
     typedef Cfg<CK, NBUF, EP> G;
     static_assert(CK % 8 == 0 && (CK * 4) % 8 == 0, "staging assigns whole rows to waves");
-    __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS + (DMAX ? 8192 : 0)];   // DMAX: + 32 KB DMA sink
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,58 +177,118 @@ __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
     const int X0 = xt * TILE_X;
 
     // ---- staging roles (fixed per thread for the whole task).  A chunk has CK*4 B rows (one per
-    // (channel, bi)) and CK*4 A rows; wave w takes B rows w, w+8, ... (lane = lattice column jb) and
-    // A row pairs 2w, 2w+1, 2w+16, ... (lane>>5 picks the row, lane&31 = ja).
-    constexpr int KB = CK / 2;   // B rows per wave per chunk: row index = 8k + w -> channel 2k + (w>>2), bi = w&3
-    constexpr int KA = CK / 4;   // A row pairs per wave per chunk: row = 16k + 2w + (lane>>5) -> channel 4k + (w>>1)
-    const int s_bi = wave & 3;
-    const int s_jb = lane;                                       // < B_COLS active
-    const int s_yb = 2 * (ib0 + s_bi) + py;                      // image row
-    const int s_xb = X0 - 2 * p.dr + 2 * s_jb;                   // image x of the even element
-    const bool b_ok = (s_jb < B_COLS) && (ib0 + s_bi >= 0) && (ib0 + s_bi < HL) && (s_xb >= 0) && (s_xb < p.W);
-    const float *b_src = b_ok ? in2n + (long)(wave >> 2) * HW + (long)s_yb * p.W + s_xb : in2n;
-    const int b_dst = (wave >> 2) * B_CH + s_bi * B_ROW + s_jb; // + k*2*B_CH, + B_PAR for the odd element
-    const int s_ai = ((wave & 1) << 1) + (lane >> 5);
-    const int s_ja = lane & 31;
-    const int s_ya = 2 * (4 * rg + s_ai) + py;
-    const int s_xa = X0 + 2 * s_ja;
-    const bool a_ok = (4 * rg + s_ai < HL) && (s_xa < p.W);
-    const float *a_src = a_ok ? in1n + (long)(wave >> 1) * HW + (long)s_ya * p.W + s_xa : in1n;
-    const int a_dst = (wave >> 1) * A_CH + s_ai * A_ROW + s_ja;  // + k*4*A_CH, + A_PAR for the odd element
-    const float b_keep = b_ok ? 1.0f : 0.0f, a_keep = a_ok ? 1.0f : 0.0f;
-    (void)b_keep; (void)a_keep;
+    // (channel, bi)) of 104 pixels (52 lattice columns x 2 parities) and CK*4 A rows of 64 pixels.
+    // X4 (dr even, W % 4 == 0): 16 B per lane -- a wave instruction covers 2 B rows (26 pieces each) or
+    // 4 A rows (16 pieces each); a piece (e,o,e,o) is de-interleaved into two ds_write_b64.
+    // otherwise: 8 B per lane, one B row (52 pairs) or two A rows (32 pairs) per wave instruction.
+    constexpr int KB = X4 ? CK / 4 : CK / 2;   // B load instructions per wave per chunk
+    constexpr int KA = X4 ? CK / 8 : CK / 4;   // A load instructions per wave per chunk
+    static_assert(!X4 || CK % 8 == 0, "X4 staging assigns 8 rows per wave");
+    typedef typename std::conditional<X4, f4, f2>::type ld_t;
+    // B
+    const int sb_piece = X4 ? (lane & 31) : lane;                    // piece / pair index within the row
+    const int sb_sub = X4 ? (lane >> 5) : 0;                         // row within the instruction
+    const int sb_x = X0 - 2 * p.dr + (X4 ? 4 : 2) * sb_piece;        // image x of the first element
+    const bool sb_col_ok = (sb_piece < (X4 ? B_COLS / 2 : B_COLS)) && (sb_x >= 0) && (sb_x < p.W);
+    // A
+    const int sa_piece = X4 ? (lane & 15) : (lane & 31);
+    const int sa_sub = X4 ? (lane >> 4) : (lane >> 5);
+    const int sa_x = X0 + (X4 ? 4 : 2) * sa_piece;
+    const bool sa_col_ok = (sa_x < p.W);
+    // row -> (channel within chunk, lattice row) for instruction k:
+    //   X4:  B row r = 8w + 2k + sub  -> ch = 2w + (k>>1), bi = 2(k&1) + sub ;  A row r = 8w + 4k + sub -> ch = 2w + k, ai = sub
+    //   else B row r = 8k + w        -> ch = 2k + (w>>2), bi = w&3          ;  A row r = 16k + 2w + sub -> ch = 4k + (w>>1), ai = 2(w&1)+sub
+    auto b_ch = [&](int k) { return X4 ? 2 * wave + (k >> 1) : 2 * k + (wave >> 2); };
+    auto b_bi = [&](int k) { return X4 ? 2 * (k & 1) + sb_sub : (wave & 3); };
+    auto a_ch = [&](int k) { return X4 ? 2 * wave + k : 4 * k + (wave >> 1); };
+    const int a_ai = X4 ? sa_sub : ((wave & 1) << 1) + sa_sub;
+    const bool a_ok = sa_col_ok && (4 * rg + a_ai < HL);
+    const long a_off = (long)(2 * (4 * rg + a_ai) + py) * p.W + sa_x;
 
-    f2 rb[KB], ra[KA];
+    ld_t rb[KB], ra[KA];
     auto stage_load = [&](int c0) {
         if (VAR & 2) return;
-        // out-of-image lanes read a valid dummy address and are zeroed by the select below: no
-        // divergent branch around the loads
+        if (VAR & 16) c0 = 0;   // profiling: every chunk re-reads chunk 0 (always L2-resident)
+        if (DMAX) {             // profiling: the chunk's bytes arrive by LDS-DMA into a sink region instead
+            // wave w: 4 instructions of 1 KB: rows (4 per instruction) x 16 pieces of 16 B
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = lane >> 4, piece = lane & 15;
+                const int ch = c0 + 2 * wave + (k >> 1);
+                const float *base = (k & 1) ? in2n : in1n;
+                int il = (k & 1) ? (ib0 + row) : (4 * rg + row);
+                il = il < 0 ? 0 : (il >= HL ? HL - 1 : il);
+                const float *g = base + (long)ch * HW + (long)(2 * il + py) * p.W + 4 * piece;
+                float *l = smem + G::LDS_FLOATS + wave * 1024 + k * 256;
+                __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+            }
+        }
+        if (VAR & 32) {         // profiling: no global loads (the LDS writes still happen)
+#pragma unroll
+            for (int k = 0; k < KB; ++k) rb[k] = (ld_t)(1.0f);
+#pragma unroll
+            for (int k = 0; k < KA; ++k) ra[k] = (ld_t)(3.0f);
+            return;
+        }
+        // Every lane loads (out-of-image lanes from a valid dummy address); the zeroing select and the parity
+        // de-interleave happen in stage_write, i.e. in program order AFTER the MFMA phase and behind its
+        // sched_barriers, so nothing forces a wait for these loads before the MFMAs have been issued.
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-            f2 v = *reinterpret_cast<const f2 *>(b_src + (b_ok ? (long)(c0 + 2 * k) * HW : 0));
-            rb[k] = b_ok ? v : (f2){0.0f, 0.0f};
+            const int il = ib0 + b_bi(k);
+            const bool ok = sb_col_ok && (il >= 0) && (il < HL);
+            rb[k] = *reinterpret_cast<const ld_t *>(in2n + (ok ? (long)(c0 + b_ch(k)) * HW + (long)(2 * il + py) * p.W + sb_x : 0));
         }
 #pragma unroll
-        for (int k = 0; k < KA; ++k) {
-            f2 v = *reinterpret_cast<const f2 *>(a_src + (a_ok ? (long)(c0 + 4 * k) * HW : 0));
-            ra[k] = a_ok ? v : (f2){0.0f, 0.0f};
-        }
+        for (int k = 0; k < KA; ++k)
+            ra[k] = *reinterpret_cast<const ld_t *>(in1n + (a_ok ? (long)(c0 + a_ch(k)) * HW + a_off : 0));
     };
     auto stage_write = [&](int buf) {
         if (VAR & 2) return;
+        if (VAR & 64) {         // profiling: loads are waited for but not written to LDS
+#pragma unroll
+            for (int k = 0; k < KB; ++k) asm volatile("" ::"v"(rb[k][0]), "v"(rb[k][1]));
+#pragma unroll
+            for (int k = 0; k < KA; ++k) asm volatile("" ::"v"(ra[k][0]), "v"(ra[k][1]));
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (DMAX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float *As = smem + buf * G::BUF_FLOATS;
         float *Bs = As + G::A_FLOATS;
-        if (s_jb < B_COLS) {
+        if (!(VAR & 32)) {   // zero the lanes that loaded the dummy address
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                Bs[b_dst + k * 2 * B_CH] = rb[k][0];
-                Bs[b_dst + k * 2 * B_CH + B_PAR] = rb[k][1];
+                const int il = ib0 + b_bi(k);
+                const bool ok = sb_col_ok && (il >= 0) && (il < HL);
+                rb[k] = ok ? rb[k] : (ld_t)(0.0f);
+            }
+#pragma unroll
+            for (int k = 0; k < KA; ++k) ra[k] = a_ok ? ra[k] : (ld_t)(0.0f);
+        }
+        if (sb_piece < (X4 ? B_COLS / 2 : B_COLS)) {
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                float *d = Bs + b_ch(k) * B_CH + b_bi(k) * B_ROW + (X4 ? 2 : 1) * sb_piece;
+                if constexpr (X4) {
+                    *reinterpret_cast<f2 *>(d) = (f2){rb[k][0], rb[k][2]};
+                    *reinterpret_cast<f2 *>(d + B_PAR) = (f2){rb[k][1], rb[k][3]};
+                } else {
+                    d[0] = rb[k][0];
+                    d[B_PAR] = rb[k][1];
+                }
             }
         }
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
-            As[a_dst + k * 4 * A_CH] = ra[k][0];
-            As[a_dst + k * 4 * A_CH + A_PAR] = ra[k][1];
+            float *d = As + a_ch(k) * A_CH + a_ai * A_ROW + (X4 ? 2 : 1) * sa_piece;
+            if constexpr (X4) {
+                *reinterpret_cast<f2 *>(d) = (f2){ra[k][0], ra[k][2]};
+                *reinterpret_cast<f2 *>(d + A_PAR) = (f2){ra[k][1], ra[k][3]};
+            } else {
+                d[0] = ra[k][0];
+                d[A_PAR] = ra[k][1];
+            }
         }
     };
 
@@ -176,14 +311,23 @@ __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
         const float *Bs = As + G::A_FLOATS;
         constexpr int KS = CK / 4;
         float af[2][2], bf[2][NV + 1];
+        if (VAR & 8) {   // profiling: operands from registers, no LDS fragment reads
 #pragma unroll
-        for (int ab = 0; ab < 2; ++ab) af[0][ab] = As[a_frag + 4 * ab];
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < NV + 1; ++j) bf[0][j] = Bs[b_frag + 4 * j];
+                for (int ab = 0; ab < 2; ++ab) af[h][ab] = (float)(lane + ab);
+#pragma unroll
+                for (int j = 0; j < NV + 1; ++j) bf[h][j] = (float)(lane - j);
+            }
+        }
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) if (!(VAR & 8)) af[0][ab] = As[a_frag + 4 * ab];
+#pragma unroll
+        for (int j = 0; j < NV + 1; ++j) if (!(VAR & 8)) bf[0][j] = Bs[b_frag + 4 * j];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < KS) {
+            if (s + 1 < KS && !(VAR & 8)) {
 #pragma unroll
                 for (int ab = 0; ab < 2; ++ab) af[nxt][ab] = As[a_frag + (s + 1) * 4 * A_CH + 4 * ab];
 #pragma unroll
@@ -230,63 +374,216 @@ __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
         }
     }
 
-    // ---- epilogue: accumulators -> LDS [ai][bi][ti][x] -> coalesced rows
-    // D layout of v_mfma_f32_16x16x4_f32: lane l, register r holds D[row = 4*(l>>4) + r][col = l&15];
-    // rows are A pixels (ai = row>>2 = l>>4, aj = row&3 = r), columns B pixels (bi = fi>>2, bj = fi&3).
-    {
-        float *Os = smem;
-        constexpr int AI_PER_PASS = 4 / EP;
-        constexpr int DUMMY = (16 / EP) * (2 * DR_MAX + 1) * O_RS;   // one spare row: sink for out-of-band entries
-        const int e_ai = fq, e_bi = fi >> 2, e_bj = fi & 3;
-        // acc / nelems as the reference forms it (correlation_cuda_kernel.cu:143); a power-of-two
-        // channel count makes the reciprocal multiply exact, otherwise divide.
-        const float fC = (float)p.C;
-        const bool pow2 = (p.C & (p.C - 1)) == 0;
-        const float rC = 1.0f / fC;
-        const int hx = lane & 31, hr = lane >> 5;   // write-out: lane = (row-in-pair, x pair)
-        const int xg = X0 + 2 * hx;
+    epilogue<NV, EP, VAR>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward kernel with LDS-DMA staging (global_load_lds_dwordx4): operands go HBM/L2 -> LDS without
+// passing through registers, in a ring of NST stages with counted vmcnt waits and ONE raw s_barrier
+// per chunk.  Same task decomposition, MFMA mapping and epilogue as corr_fwd_mfma_f32 above; only the
+// LDS image differs, because a DMA instruction writes 64 lanes x 16 B = 1 KB of CONSECUTIVE LDS:
+//   B tile  [ch][bi][x]   104 floats per row (x from X0-2dr, parity interleaved), channel stride 420;
+//           the 4 rows of a channel are 104 16-byte pieces = 2 DMA instructions (64 + 40 lanes)
+//   A tile  [ch][ai][x]   64 floats per row, stored ROTATED by 8*ai floats (the DMA's per-lane GLOBAL
+//           address is free, so lane (row, piece) fetches piece (piece - 2*ai) mod 16): the four rows of an
+//           A block then sit on different banks; one DMA instruction per channel
+// Pieces outside the image are never written: the ring is zero-filled once and stays zero there.
+// Operand reads are ds_read_b32 at parity stride 2: the 16 pixels of a block cover the 16 banks of one
+// parity and the two k-slots of a 32-lane group collide 2-way (LDS is far from saturated).
+// Preconditions on top of the register-staged kernel: dr even, W % 4 == 0 (pieces are 4-pixel aligned).
+constexpr int DB_ROW = 104, DB_CH = 4 * DB_ROW + 4;   // 420 floats: 16 B aligned, rows 8 banks apart
+constexpr int DA_ROW = 64, DA_CH = 4 * DA_ROW;        // 256 floats
+
+template <int CK, int NST, int EP>
+struct DCfg {
+    static constexpr int A_FLOATS = CK * DA_CH, B_FLOATS = CK * DB_CH, ST_FLOATS = A_FLOATS + B_FLOATS;
+    static constexpr int O_FLOATS = (16 / EP) * (2 * DR_MAX + 1) * O_RS + 64;
+    static constexpr int LDS_FLOATS = (NST * ST_FLOATS > O_FLOATS) ? NST * ST_FLOATS : O_FLOATS;
+};
+
+// NLD = 0: every wave stages its share of a chunk and computes (8 waves).
+// NLD > 0: wave specialisation -- waves 0..7 only read operands and issue MFMAs, waves 8..8+NLD-1 only issue
+// the DMAs.  A CU's memory pipeline accepts VMEM instructions at roughly 11-19 B/clk and issue is in order,
+// so a wave that stages its own data sits in VMEM issue for 1000-1800 clocks per chunk with its MFMAs
+// queued behind; loader waves absorb that stall while the matrix pipe keeps running.
+template <int NV, int CK, int NST, int EP, int WPS, int VAR, int NLD = 0>
+__global__ __launch_bounds__(512 + 64 * NLD, (NLD ? (8 + NLD + 3) / 4 : WPS)) void corr_fwd_mfma_dma(Args p)
+{
+    typedef DCfg<CK, NST, EP> G;
+    constexpr int NLW = NLD ? NLD : 8;            // waves that issue DMAs
+    constexpr int NW = 8 + NLD;                   // waves in the workgroup
+    static_assert((CK * 3) % NLW == 0, "3 DMA instructions per channel are spread evenly over the loading waves");
+    constexpr int DPW = CK * 3 / NLW;   // DMA instructions per loading wave per chunk
+    __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int u = (int)(t % NV); t /= NV;
+    const int xt = (int)(t % p.NXT); t /= p.NXT;
+    const int rg = (int)(t % p.NRG); t /= p.NRG;
+    const int py = (int)(t & 1u);
+    const int n = (int)(t >> 1);
+
+    const int HL = p.H >> 1;
+    const int ib0 = 4 * rg - p.dr + 4 * u;
+    const bool all_pad = (ib0 + 3 < 0) || (ib0 >= HL);
+    const long HW = (long)p.H * p.W;
+    const float *in1n = p.in1 + (long)n * p.C * HW;
+    const float *in2n = p.in2 + (long)n * p.C * HW;
+    const int X0 = xt * TILE_X;
+
+    // ---- DMA roles.  Instruction j (0 .. 3*CK-1) of a chunk: channel j/3, kind j%3
+    //   kind 0: B pieces 0..63   kind 1: B pieces 64..103 (lanes 0..39)   kind 2: the A rows
+    // loading wave lw issues instructions lw*DPW .. lw*DPW+DPW-1.  Per-lane source offsets (within a channel
+    // plane) and validity do not depend on the chunk.
+    const bool is_loader = NLD ? (wave >= 8) : true;
+    const bool is_consumer = NLD ? (wave < 8) : true;
+    const int lw = NLD ? (wave >= 8 ? wave - 8 : 0) : wave;
+    int d_off[DPW];     // element offset inside the channel plane, or -1
+    int d_ch[DPW];      // channel within the chunk
+    int d_lds[DPW];     // LDS float offset of the instruction's 1 KB window inside a stage
+    bool d_isA[DPW];
 #pragma unroll
-        for (int pass = 0; pass < EP; ++pass) {
-            const bool mine = (EP == 1) || ((e_ai / AI_PER_PASS) == pass);
-            const int plane = ((e_ai % AI_PER_PASS) * 4 + e_bi) * p.D;
+    for (int k = 0; k < DPW; ++k) {
+        const int j = lw * DPW + k;
+        const int ch = j / 3, kind = j % 3;
+        d_ch[k] = ch;
+        d_isA[k] = (kind == 2);
+        int off = -1;
+        if (kind == 2) {
+            const int row = lane >> 4, slot = lane & 15;
+            const int piece = (slot - 2 * row) & 15;            // row `ai` is stored rotated by 2*ai pieces
+            const int IL = 4 * rg + row, x0 = X0 + 4 * piece;
+            if (IL < HL && x0 < p.W) off = (2 * IL + py) * p.W + x0;
+            d_lds[k] = ch * DA_CH;
+        } else {
+            const int i = kind * 64 + lane;                     // piece index within the channel's 4 rows
+            const int row = i / 26, pc = i - row * 26;
+            const int il = ib0 + row, x0 = X0 - 2 * p.dr + 4 * pc;
+            if (i < 104 && il >= 0 && il < HL && x0 >= 0 && x0 < p.W) off = (2 * il + py) * p.W + x0;
+            d_lds[k] = G::A_FLOATS + ch * DB_CH + kind * 256;
+        }
+        d_off[k] = off;
+    }
+    // an instruction none of whose lanes is inside the image is skipped entirely, so the number of DMAs this
+    // wave has in flight per chunk is counted, not assumed (the vmcnt waits below depend on it)
+    int n_dma = 0;
 #pragma unroll
-            for (int ab = 0; ab < 2; ++ab)
+    for (int k = 0; k < DPW; ++k) n_dma += (__ballot(d_off[k] >= 0) != 0ull) ? 1 : 0;
+    n_dma = __builtin_amdgcn_readfirstlane(n_dma);
+    auto wait_younger = [&](int chunks) {   // wait until at most chunks * n_dma DMAs are outstanding
+        const int lim = chunks * n_dma;
+        switch (lim) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // conservative
+        }
+    };
+    auto dma_issue = [&](int c0, int stage) {
+        if ((VAR & 2) || !is_loader) return;
+        float *st = smem + stage * G::ST_FLOATS;
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) {
+            const float *src = (d_isA[k] ? in1n : in2n) + (long)(c0 + d_ch[k]) * HW + d_off[k];
+            if (d_off[k] >= 0)
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(st + d_lds[k]), 16, 0, 0);
+        }
+    };
+
+    // ---- MFMA roles (as in corr_fwd_mfma_f32)
+    const int xpar = wave & 1;
+    const int a0 = (wave >> 1) << 1;
+    const int fi = lane & 15, fq = lane >> 4;
+    const int f_row = fi >> 2, f_col = fi & 3;
+    int a_frag[2];
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab)
+        a_frag[ab] = fq * DA_CH + f_row * DA_ROW + ((2 * (4 * (a0 + ab) + f_col) + xpar + 8 * f_row) & 63);
+    const int b_frag = G::A_FLOATS + fq * DB_CH + f_row * DB_ROW + 2 * (4 * a0 + f_col) + xpar;   // + 8*j per block column
+
+    f4 acc[2][NV];
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[ab][v] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto mma_chunk = [&](int stage) {
+        const float *st = smem + stage * G::ST_FLOATS;
+        constexpr int KS = CK / 4;
+        float af[2][2], bf[2][NV + 1];
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) af[0][ab] = st[a_frag[ab]];
+#pragma unroll
+        for (int j = 0; j < NV + 1; ++j) bf[0][j] = st[b_frag + 8 * j];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int ab = 0; ab < 2; ++ab) af[nxt][ab] = st[a_frag[ab] + (s + 1) * 4 * DA_CH];
+#pragma unroll
+                for (int j = 0; j < NV + 1; ++j) bf[nxt][j] = st[b_frag + (s + 1) * 4 * DB_CH + 8 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (VAR & 1) {
+#pragma unroll
+                for (int ab = 0; ab < 2; ++ab) asm volatile("" ::"v"(af[cur][ab]));
+#pragma unroll
+                for (int j = 0; j < NV + 1; ++j) asm volatile("" ::"v"(bf[cur][j]));
+            } else {
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ti = 4 * v + e_bj - r;
-                        const int x = 2 * (4 * (a0 + ab) + r) + xpar;
-                        bool ok = mine;
-                        if (v == 0) ok = ok && (ti >= 0);            // only the first and the last two block columns
-                        if (v >= NV - 2) ok = ok && (ti < p.D);      // can fall outside the displacement band
-                        const int addr = ok ? (plane + ti) * O_RS + x : DUMMY + lane;
-                        if (EP == 1 || mine) Os[addr] = acc[ab][v][r];
-                    }
-            __syncthreads();
-            // each wave writes whole planes: rows (plane, ti) for ti = 0..D-1, two rows per instruction,
-            // 8 B per lane -> one 256 B contiguous segment per row
-            for (int pl = wave; pl < 4 * AI_PER_PASS; pl += 8) {
-                const int ai = pass * AI_PER_PASS + (pl >> 2), bi = pl & 3;
-                const int tj = 4 * u + bi - ai;
-                const int IL = 4 * rg + ai;
-                if (tj < 0 || tj >= p.D || IL >= HL) continue; // wave-uniform
-                const int y = 2 * IL + py;
-                float *orow = p.out + (((long)n * p.D * p.D + (long)tj * p.D) * p.H + y) * p.W + xg;
-                const float *srow = Os + (long)pl * p.D * O_RS + 2 * hx;
-                for (int ti0 = 0; ti0 < p.D; ti0 += 2) {
-                    const int ti = ti0 + hr;
-                    if (ti < p.D && xg < p.W && !(VAR & 4)) {
-                        f2 val = *reinterpret_cast<const f2 *>(srow + ti * O_RS);
-                        if (pow2) { val[0] *= rC; val[1] *= rC; }
-                        else { val[0] /= fC; val[1] /= fC; }
-                        *reinterpret_cast<f2 *>(orow + (long)ti * HW) = val;
-                    }
-                }
+                    for (int ab = 0; ab < 2; ++ab)
+                        acc[ab][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][ab], bf[cur][ab + v], acc[ab][v], 0, 0, 0);
             }
-            if (pass + 1 < EP) __syncthreads();
         }
+    };
+
+    const int nchunks = all_pad ? 0 : p.C / CK;
+    if (nchunks > 0) {
+        // zero the ring once: positions outside the image are never written by the DMA
+        for (int i = tid; i < NST * G::ST_FLOATS / 4; i += 64 * NW) reinterpret_cast<f4 *>(smem)[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+        // prologue: NST-1 chunks in flight
+#pragma unroll
+        for (int c = 0; c < NST - 1; ++c)
+            if (c < nchunks) dma_issue(c * CK, c);
+        // profiling (VAR & 8): wave 0 of two fixed interior tasks records s_memtime at 5 points of every chunk
+        const bool task_a = (n == 0 && py == 0 && rg == 2 && u == 2), task_b = (n == 3 && py == 1 && rg == 3 && u == 3);
+        const bool stamp = (VAR & 8) && p.dbg && wave == 0 && (task_a || task_b);
+        unsigned long long *dbg = p.dbg ? p.dbg + (task_a ? 0 : 1024) : nullptr;
+#define FN2_STAMP(i) if ((VAR & 8) && stamp && lane == 0) dbg[ck * 8 + (i)] = __builtin_amdgcn_s_memtime();
+        for (int ck = 0; ck < nchunks; ++ck) {
+            FN2_STAMP(0)
+            // chunk ck has landed once at most the DMAs of the (NST-2) younger chunks are outstanding; the
+            // tail (fewer younger chunks issued) simply drains everything.
+            if (is_loader) {
+                if (ck + NST - 2 < nchunks) wait_younger(NST - 2);
+                else wait_younger(0);
+            }
+            FN2_STAMP(1)
+            __builtin_amdgcn_s_barrier();   // every wave's share of chunk ck is visible; stage (ck-1)%NST is free
+            FN2_STAMP(2)
+            if (ck + NST - 1 < nchunks) dma_issue((ck + NST - 1) * CK, (ck + NST - 1) % NST);
+            FN2_STAMP(3)
+            if (is_consumer) mma_chunk(ck % NST);
+            FN2_STAMP(4)
+        }
+#undef FN2_STAMP
+        __syncthreads();   // all operand reads done before the epilogue reuses the ring
     }
+    epilogue<NV, EP, VAR, NW>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
 }
 
 } // namespace mf
@@ -306,7 +603,12 @@ namespace mf {
 template <int NV, int CK, int NBUF, int EP, int WPS, int VAR>
 static int launch(const Args &a, long ntasks, hipStream_t s)
 {
-    hipLaunchKernelGGL((corr_fwd_mfma_f32<NV, CK, NBUF, EP, WPS, VAR>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
+    // 16-byte staging needs the tile's first halo column and the image width on 4-pixel boundaries
+    const bool x4 = (a.dr % 2 == 0) && (a.W % 4 == 0) && aligned(a.in1, 16) && aligned(a.in2, 16) && !(VAR & 128);
+    if (x4)
+        hipLaunchKernelGGL((corr_fwd_mfma_f32<NV, CK, NBUF, EP, WPS, VAR & 127, true>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
+    else
+        hipLaunchKernelGGL((corr_fwd_mfma_f32<NV, CK, NBUF, EP, WPS, VAR & 127, false>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
     return launch_status();
 }
 
@@ -325,12 +627,16 @@ static int launch_nv(const Args &a, long ntasks, hipStream_t s)
 
 } // namespace mf
 
-// tune: 0 = shipped configuration; 100 + 8*cfg + var = profiling instantiations (NV = 6 only)
+static unsigned long long *g_corr_dbg = nullptr;   // profiling only (fn2_debug_set_buffer); never set in production
+void corr_set_debug_buffer(void *p) { g_corr_dbg = static_cast<unsigned long long *>(p); }
+
+// tune: 0 = shipped configuration; 100 + 256*cfg + var = profiling instantiations (NV = 6 only)
 int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
                           int tune, hipStream_t s)
 {
     if (!aligned(in1, 8) || !aligned(in2, 8)) return FN2_EALIGN;
     mf::Args a;
+    a.dbg = g_corr_dbg;
     a.in1 = in1; a.in2 = in2; a.out = out;
     a.C = C; a.H = H; a.W = W;
     a.dr = md / 2; a.D = 2 * a.dr + 1; a.NV = 1 + (a.dr + 1) / 2;
@@ -339,25 +645,68 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
     a.NXT = (W + mf::TILE_X - 1) / mf::TILE_X;
     const long ntasks = (long)B * 2 * a.NRG * a.NXT * a.NV;
     if (ntasks == 0) return FN2_OK;
+    const bool dma_ok = (a.dr % 2 == 0) && (W % 4 == 0) && aligned(in1, 16) && aligned(in2, 16);
+    if (tune >= 1000) {   // LDS-DMA staging, profiling configurations (NV = 6 only)
+        if (!dma_ok || a.NV != 6 || C % 16 != 0) return FN2_EUNSUPPORTED;
+#define FN2_DMA(CK, NST, EP, WPS, V)                                                                             \
+    hipLaunchKernelGGL((mf::corr_fwd_mfma_dma<6, CK, NST, EP, WPS, V>), dim3((unsigned)ntasks), dim3(512), 0, s, a); \
+    return launch_status();
+#define FN2_WS(CK, NST, EP, V, NLD)                                                                              \
+    hipLaunchKernelGGL((mf::corr_fwd_mfma_dma<6, CK, NST, EP, 2, V, NLD>), dim3((unsigned)ntasks),               \
+                       dim3(512 + 64 * NLD), 0, s, a);                                                           \
+    return launch_status();
+        switch (tune) {
+        case 1000: FN2_DMA(8, 3, 2, 4, 0)
+        case 1001: FN2_DMA(8, 3, 2, 4, 1)
+        case 1002: FN2_DMA(8, 3, 2, 4, 2)
+        case 1010: FN2_DMA(16, 3, 1, 2, 0)
+        case 1011: FN2_DMA(16, 3, 1, 2, 1)
+        case 1020: FN2_DMA(8, 4, 2, 2, 0)
+        case 1030: FN2_DMA(16, 2, 1, 2, 0)
+        case 1040: FN2_DMA(8, 2, 2, 4, 0)
+        case 1008: FN2_DMA(8, 3, 2, 4, 8)
+        case 1009: FN2_DMA(8, 3, 2, 4, 9)
+        case 1038: FN2_DMA(16, 2, 1, 2, 8)
+        case 1100: FN2_WS(8, 4, 2, 0, 4)     // 4 loader waves, 4 stages of 8 channels (86 KB)
+        case 1101: FN2_WS(8, 4, 2, 1, 4)
+        case 1108: FN2_WS(8, 4, 2, 8, 4)
+        case 1110: FN2_WS(16, 3, 1, 0, 4)    // 4 loader waves, 3 stages of 16 channels (130 KB)
+        case 1120: FN2_WS(8, 3, 2, 0, 4)     // 65 KB: two workgroups per CU
+        case 1130: FN2_WS(8, 4, 2, 0, 2)     // 2 loader waves
+        case 1140: FN2_WS(16, 3, 1, 0, 2)
+        default: return FN2_EUNSUPPORTED;
+        }
+#undef FN2_DMA
+#undef FN2_WS
+    }
+    if (tune == 0 && dma_ok && a.NV == 6) {   // FlowNetC's radius: LDS-DMA staging, 2 stages of 16 channels
+        hipLaunchKernelGGL((mf::corr_fwd_mfma_dma<6, 16, 2, 1, 2, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
+        return launch_status();
+    }
     if (tune == 0) return mf::launch_nv<16, 1, 2, 4, 0>(a, ntasks, s);   // 47 KB LDS: two workgroups per CU
     if (tune < 100 || a.NV != 6 || C % 32 != 0) return FN2_EUNSUPPORTED;
-    const int cfg = (tune - 100) / 8, var = (tune - 100) % 8;
-#define FN2_VARS(CK, NBUF, EP, WPS)                                                   \
-    switch (var) {                                                                    \
-    case 0: return mf::launch<6, CK, NBUF, EP, WPS, 0>(a, ntasks, s);                 \
-    case 1: return mf::launch<6, CK, NBUF, EP, WPS, 1>(a, ntasks, s);                 \
-    case 2: return mf::launch<6, CK, NBUF, EP, WPS, 2>(a, ntasks, s);                 \
-    case 3: return mf::launch<6, CK, NBUF, EP, WPS, 3>(a, ntasks, s);                 \
-    case 4: return mf::launch<6, CK, NBUF, EP, WPS, 4>(a, ntasks, s);                 \
-    default: return FN2_EUNSUPPORTED;                                                 \
+    const int cfg = (tune - 100) / 256, var = (tune - 100) % 256;   // var bit 7: force the 8-byte staging path
+#define FN2_V(CK, NBUF, EP, WPS, V) case V: return mf::launch<6, CK, NBUF, EP, WPS, V>(a, ntasks, s);
+#define FN2_VARS(CK, NBUF, EP, WPS)                                                                           \
+    switch (var) {                                                                                            \
+        FN2_V(CK, NBUF, EP, WPS, 0) FN2_V(CK, NBUF, EP, WPS, 1) FN2_V(CK, NBUF, EP, WPS, 2)                   \
+        FN2_V(CK, NBUF, EP, WPS, 3) FN2_V(CK, NBUF, EP, WPS, 4) FN2_V(CK, NBUF, EP, WPS, 5)                   \
+        FN2_V(CK, NBUF, EP, WPS, 6) FN2_V(CK, NBUF, EP, WPS, 7) FN2_V(CK, NBUF, EP, WPS, 14)                  \
+        FN2_V(CK, NBUF, EP, WPS, 16) FN2_V(CK, NBUF, EP, WPS, 32) FN2_V(CK, NBUF, EP, WPS, 33)                \
+        FN2_V(CK, NBUF, EP, WPS, 37) FN2_V(CK, NBUF, EP, WPS, 64) FN2_V(CK, NBUF, EP, WPS, 65)                \
+        FN2_V(CK, NBUF, EP, WPS, 69) FN2_V(CK, NBUF, EP, WPS, 128)                                            \
+    default: return FN2_EUNSUPPORTED;                                                                         \
+    }
+    if (cfg == 2) {   // LDS-DMA cost experiment: cfg 1 with constant operands + the chunk bytes DMA'd into a sink
+        hipLaunchKernelGGL((mf::corr_fwd_mfma_f32<6, 16, 1, 2, 4, 32, true, true>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
+        return launch_status();
     }
     switch (cfg) {
     case 0: FN2_VARS(16, 2, 1, 2)   // 94 KB LDS, 1 workgroup / CU
     case 1: FN2_VARS(16, 1, 2, 4)   // 47 KB LDS, 2 workgroups / CU, 2 barriers per chunk
-    case 2: FN2_VARS(8, 2, 2, 4)    // 47 KB LDS, 2 workgroups / CU, 1 barrier per 8-channel chunk
-    case 3: FN2_VARS(32, 1, 1, 2)   // 94 KB LDS, 1 workgroup / CU, 32-channel chunks
     default: return FN2_EUNSUPPORTED;
     }
+#undef FN2_V
 #undef FN2_VARS
 }
 
