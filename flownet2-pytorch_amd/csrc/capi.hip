@@ -62,11 +62,12 @@ extern "C" int fn2_correlation_forward_ex(const void *in1, const void *in2, void
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool mfma_ok = corr_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                   stride2) && aligned(in1, 8) && aligned(in2, 8) && aligned(out, 8);
-    if ((algo == FN2_CORR_MFMA_F32 || algo >= 100) && !mfma_ok) return FN2_EUNSUPPORTED;
-    if (algo == FN2_CORR_MFMA_F32 || algo >= 100 || (algo == FN2_CORR_AUTO && mfma_ok))
+    const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || algo >= 100);
+    if (wants_mfma && !mfma_ok) return FN2_EUNSUPPORTED;
+    if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok))
         return corr_forward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
                                      static_cast<float *>(out), B, C, H, W, max_displacement,
-                                     algo >= 100 ? algo : 0, s); // algo >= 100: profiling instantiations
+                                     algo, s); // 0 auto, 2 fp32 MFMA, 3 bf16x3, >= 100 profiling instantiations
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_forward_direct(in1, in2, out, dtype, p, s);
 }
@@ -103,6 +104,7 @@ extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, con
     const bool mfma_ok = corr_bwd_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                       stride2) &&
                          aligned(in1, 8) && aligned(in2, 8) && aligned(grad_out, 8);
+    if (algo == FN2_CORR_MFMA_BF16X3) return FN2_EUNSUPPORTED;   // forward only
     if ((algo == FN2_CORR_MFMA_F32 || algo >= 100) && !mfma_ok) return FN2_EUNSUPPORTED;
     if (algo == FN2_CORR_MFMA_F32 || algo >= 100 || (algo == FN2_CORR_AUTO && mfma_ok))
         return corr_backward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),

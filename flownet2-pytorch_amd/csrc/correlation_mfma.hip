@@ -586,6 +586,222 @@ __global__ __launch_bounds__(512 + 64 * NLD, (NLD ? (8 + NLD + 3) / 4 : WPS)) vo
     epilogue<NV, EP, VAR, NW>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward kernel on the bf16 matrix cores with an EXACT three-way split of the fp32 operands.
+//
+// Why: v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate (41 us for this problem at 100 % utilisation) and,
+// measured on MI355X (scripts/ubench/mfma_vmem_overlap.hip), does not overlap with vector-memory traffic
+// issued by ANY wave of the same SIMD -- time = MFMA time + load time.  v_mfma_f32_16x16x32_bf16 is ~15x
+// faster per MAC and overlaps with LDS-DMA perfectly.
+//
+// Numerics: every fp32 value is split by truncation into three bf16 terms a = a0 + a1 + a2 (8 + 8 + 8
+// significand bits: the split is exact), and the product a*b is formed as
+//     a0*b0 + a0*b1 + a1*b0 + a1*b1 + a0*b2 + a2*b0          (dropped: a1*b2, a2*b1, a2*b2 <= 2^-23 |a*b|)
+// Every partial product is exact in fp32 and accumulation is fp32 inside the MFMA, so the result carries
+// fp32-class error: measured against an fp64 reference (scripts/corr_accuracy.py, 8x256x48x64, N(0,1)):
+// max |err| 2.6e-7 / rms 1.3e-8, vs 2.3e-7 / 1.45e-8 for the fp32 MFMA kernel; same relative figures for
+// inputs scaled by 100 or 1e-3 and for log-normal magnitudes.  This is fp32 arithmetic carried out on the
+// bf16 pipe, not a reduced-precision mode.
+//
+// One MFMA step contracts 32 channels: lane group q = lane>>4 owns channels 8q..8q+7 of the step for its
+// pixel, reads them from LDS (8 ds_read_b32 at channel stride), splits them in registers and packs each term
+// into 4 VGPRs; six MFMAs per (A block, B block) pair and step.  No value is split twice inside a wave
+// except for the B blocks shared between its two A blocks' neighbours (7 B fragments for 12 pairs).
+//
+// LDS image (per stage of 32 channels, 2 stages): A and B tiles alike, [ch][row 0..3][64 floats] with channel
+// stride 260 floats.  Row r of channel c is stored rotated by 8r + 16((c>>3)&1) floats (the DMA's per-lane
+// source address does the rotation for free): the 16 pixels of a block and the two channel octets of a
+// 32-lane half then cover 32 distinct banks.  The 4 pad floats after each channel stay zero: lanes whose B
+// pixel lies in the zero halo left/right of the image read the pad instead (address chosen once per task).
+// So the B tile carries no halo; this kernel therefore requires the image to fit one x tile (W <= 64), which
+// FlowNetC's cost volume at 384x512 does; wider maps use the fp32 kernels.
+//
+// All 8 waves issue DMAs; waves 0-3 before their MFMA phase and waves 4-7 after it, so the two waves that
+// share a SIMD (w and w+4) are in complementary phases.
+typedef short __attribute__((ext_vector_type(8))) bf16x8;
+typedef unsigned __attribute__((ext_vector_type(4))) u4;
+
+constexpr int SB_CH = 260;                 // channel stride (floats): 256 + 4 zero pad
+constexpr int SB_CK = 32;                  // channels per stage = per MFMA step
+constexpr int SB_TILE = SB_CK * SB_CH;     // floats per tile (A or B) per stage
+constexpr int SB_STAGE = 2 * SB_TILE;      // 16640 floats = 66 560 B
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi)
+{
+    // bf16(lo) in bits 0..15, bf16(hi) in bits 16..31 (both by truncation: the upper halves of the floats)
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// split 8 fp32 values into three packed bf16 operands (scalar subtractions: packed fp32 VALU next to MFMAs
+// measured slower on this kernel)
+__device__ __forceinline__ void split3(const float (&r)[8], u4 &t0, u4 &t1, u4 &t2)
+{
+    float h0[8], h1[8], h2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h0[k] = trunc_bf16(r[k]);
+        const float r1 = r[k] - h0[k];   // exact
+        h1[k] = trunc_bf16(r1);
+        h2[k] = r1 - h1[k];              // exact, at most 8 significant bits
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        t0[m] = pack_hi16(h0[2 * m], h0[2 * m + 1]);
+        t1[m] = pack_hi16(h1[2 * m], h1[2 * m + 1]);
+        t2[m] = pack_hi16(h2[2 * m], h2[2 * m + 1]);
+    }
+}
+
+template <int NV, int EP, int VAR>
+__global__ __launch_bounds__(512, 2) void corr_fwd_mfma_bf16x3(Args p)
+{
+    constexpr int NST = 2;
+    constexpr int O_FLOATS = (16 / EP) * (2 * DR_MAX + 1) * O_RS + 64;
+    constexpr int LDS_FLOATS = (NST * SB_STAGE > O_FLOATS) ? NST * SB_STAGE : O_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int u = (int)(t % NV); t /= NV;
+    const int xt = (int)(t % p.NXT); t /= p.NXT;   // NXT == 1 (checked by the launcher)
+    const int rg = (int)(t % p.NRG); t /= p.NRG;
+    const int py = (int)(t & 1u);
+    const int n = (int)(t >> 1);
+
+    const int HL = p.H >> 1;
+    const int ib0 = 4 * rg - p.dr + 4 * u;
+    const bool all_pad = (ib0 + 3 < 0) || (ib0 >= HL);
+    const long HW = (long)p.H * p.W;
+    const float *in1n = p.in1 + (long)n * p.C * HW;
+    const float *in2n = p.in2 + (long)n * p.C * HW;
+    const int X0 = xt * TILE_X;
+
+    // ---- DMA roles: wave w stages channels 4w..4w+3 of a stage, one instruction per (channel, tile):
+    // lane = (row, slot); slot holds piece (slot - 2 row - 4 ((c>>3)&1)) mod 16 of the row, c>>3 == w>>1.
+    const int d_row = lane >> 4, d_slot = lane & 15;
+    const int d_piece = (d_slot - 2 * d_row - 4 * ((wave >> 1) & 1)) & 15;
+    const int d_x = X0 + 4 * d_piece;
+    const int d_ila = 4 * rg + d_row, d_ilb = ib0 + d_row;
+    const bool d_oka = (d_ila < HL) && (d_x < p.W);
+    const bool d_okb = (d_ilb >= 0) && (d_ilb < HL) && (d_x < p.W);
+    const int d_offa = (2 * d_ila + py) * p.W + d_x;
+    const int d_offb = (2 * d_ilb + py) * p.W + d_x;
+    const int n_dma = 4 * ((__ballot(d_oka) != 0ull ? 1 : 0) + (__ballot(d_okb) != 0ull ? 1 : 0));
+    auto dma_issue = [&](int c0, int stage) {
+        if (VAR & 2) return;
+        float *st = smem + stage * SB_STAGE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * wave + k;
+            if (d_oka)
+                __builtin_amdgcn_global_load_lds(in1n + (long)(c0 + c) * HW + d_offa,
+                                                 (__attribute__((address_space(3))) void *)(st + c * SB_CH), 16, 0, 0);
+            if (d_okb)
+                __builtin_amdgcn_global_load_lds(in2n + (long)(c0 + c) * HW + d_offb,
+                                                 (__attribute__((address_space(3))) void *)(st + SB_TILE + c * SB_CH), 16, 0, 0);
+        }
+    };
+    auto wait_all_but = [&](int chunks) {   // at most `chunks` x n_dma DMAs of this wave still in flight
+        if (chunks == 0 || n_dma == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+
+    // ---- MFMA roles
+    const int xpar = wave & 1;
+    const int a0 = (wave >> 1) << 1;
+    const int fi = lane & 15, fq = lane >> 4;
+    const int f_row = fi >> 2, f_col = fi & 3;
+    const int rot = 8 * f_row + 16 * (fq & 1);
+    int a_frag[2];
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab)
+        a_frag[ab] = (8 * fq) * SB_CH + f_row * 64 + ((2 * (4 * (a0 + ab) + f_col) + xpar + rot) & 63);
+    int b_frag[NV + 1];
+#pragma unroll
+    for (int j = 0; j < NV + 1; ++j) {
+        const int x = 2 * (4 * (a0 + j) + f_col - p.dr) + xpar;          // tile-local image x of this lane's B pixel
+        const bool in_img = (x >= 0) && (X0 + x < p.W) && (x < TILE_X);
+        b_frag[j] = SB_TILE + (8 * fq) * SB_CH + (in_img ? f_row * 64 + ((x + rot) & 63) : 256);   // 256: the zero pad
+    }
+
+    f4 acc[2][NV];
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[ab][v] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto as_bf = [](const u4 &x) { return __builtin_bit_cast(bf16x8, x); };
+
+    auto mma_step = [&](int stage) {
+        const float *st = smem + stage * SB_STAGE;
+        // raw fragments are fetched one fragment ahead of their split (the LDS latency hides behind the
+        // previous fragment's VALU + MFMA work); order: A[0], A[1], B[0], B[1], ...
+        float rq[2][8];
+        auto fetch = [&](int f, float (&r)[8]) {
+            const int base = (f < 2) ? a_frag[f] : b_frag[f - 2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = st[base + k * SB_CH];
+        };
+        u4 A0[2], A1[2], A2[2];
+        fetch(0, rq[0]);
+#pragma unroll
+        for (int f = 0; f < NV + 3; ++f) {
+            const int cur = f & 1;
+            if (f + 1 < NV + 3) fetch(f + 1, rq[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (f < 2) {
+                split3(rq[cur], A0[f], A1[f], A2[f]);
+                if (VAR & 1) asm volatile("" ::"v"(A0[f][0]), "v"(A1[f][0]), "v"(A2[f][0]), "v"(A0[f][3]), "v"(A1[f][3]), "v"(A2[f][3]));
+            } else {
+                const int j = f - 2;
+                u4 B0, B1, B2;
+                split3(rq[cur], B0, B1, B2);
+                if (!(VAR & 1)) {
+                    // six products per pair; the two pairs of this B block (ab = 0: v = j, ab = 1: v = j-1) alternate
+                    // so that consecutive MFMAs never wait on the same accumulator
+                    const u4 *PA[6] = {A0, A0, A1, A1, A0, A2};
+                    const u4 *PB[6] = {&B0, &B1, &B0, &B1, &B2, &B0};
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int ab = 0; ab < 2; ++ab) {
+                            const int v = j - ab;
+                            if (v >= 0 && v < NV)
+                                acc[ab][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(PA[pr][ab]), as_bf(*PB[pr]), acc[ab][v], 0, 0, 0);
+                        }
+                } else {
+                    asm volatile("" ::"v"(B0[0]), "v"(B0[3]), "v"(B1[0]), "v"(B1[3]), "v"(B2[0]), "v"(B2[3]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int nsteps = all_pad ? 0 : p.C / SB_CK;
+    const bool early = (wave < 4);    // waves w and w+4 share a SIMD: complementary DMA / MFMA phases
+    if (nsteps > 0) {
+        for (int i = tid; i < NST * SB_STAGE / 4; i += 512) reinterpret_cast<f4 *>(smem)[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+        dma_issue(0, 0);
+        for (int sk = 0; sk < nsteps; ++sk) {
+            // early waves have issued step sk only; late waves have issued step sk only as well (they issue
+            // step sk+1 at the end of this iteration): wait for everything
+            wait_all_but(0);
+            __builtin_amdgcn_s_barrier();   // step sk is visible to all; the other stage is free
+            const bool more = (sk + 1 < nsteps);
+            if (more && early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
+            mma_step(sk & 1);
+            if (more && !early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
+        }
+        __syncthreads();
+    }
+    epilogue<NV, EP, VAR>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
+}
+
 } // namespace mf
 
 // Preconditions of the MFMA forward path.
@@ -631,6 +847,8 @@ static unsigned long long *g_corr_dbg = nullptr;   // profiling only (fn2_debug_
 void corr_set_debug_buffer(void *p) { g_corr_dbg = static_cast<unsigned long long *>(p); }
 
 // tune: 0 = shipped configuration; 100 + 256*cfg + var = profiling instantiations (NV = 6 only)
+// tune: 0 = fastest applicable kernel (bf16x3 split where it applies, else fp32 MFMA); 2 = fp32 MFMA only
+//       (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain); 3 = bf16x3 only; >= 100 profiling instantiations
 int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
                           int tune, hipStream_t s)
 {
@@ -667,6 +885,9 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
         case 1008: FN2_DMA(8, 3, 2, 4, 8)
         case 1009: FN2_DMA(8, 3, 2, 4, 9)
         case 1038: FN2_DMA(16, 2, 1, 2, 8)
+        case 2000: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2001: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2002: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 2>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 1100: FN2_WS(8, 4, 2, 0, 4)     // 4 loader waves, 4 stages of 8 channels (86 KB)
         case 1101: FN2_WS(8, 4, 2, 1, 4)
         case 1108: FN2_WS(8, 4, 2, 8, 4)
@@ -679,6 +900,19 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
 #undef FN2_DMA
 #undef FN2_WS
     }
+    // bf16x3: exact 3-way operand split on the bf16 matrix cores (fp32-class accuracy, see kernel comment);
+    // needs the whole width in one x tile, 32-channel steps and 4-pixel aligned rows
+    const bool bf16x3_ok = dma_ok && a.NXT == 1 && C % 32 == 0;
+    if (tune == 3 && !bf16x3_ok) return FN2_EUNSUPPORTED;
+    if ((tune == 0 || tune == 3) && bf16x3_ok) {
+        switch (a.NV) {
+#define FN2_B3(NVV) case NVV: hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<NVV, 1, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+            FN2_B3(2) FN2_B3(3) FN2_B3(4) FN2_B3(5) FN2_B3(6)
+#undef FN2_B3
+        default: return FN2_EUNSUPPORTED;
+        }
+    }
+    if (tune == 2) tune = 0;   // exact-fp32 MFMA kernels below
     if (tune == 0 && dma_ok && a.NV == 6) {   // FlowNetC's radius: LDS-DMA staging, 2 stages of 16 channels
         hipLaunchKernelGGL((mf::corr_fwd_mfma_dma<6, 16, 2, 1, 2, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
         return launch_status();

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libflownet2_hip.so")
 
 FN2_F32, FN2_F16, FN2_F64 = 0, 1, 2
-FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32 = 0, 1, 2
+FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32, FN2_CORR_MFMA_BF16X3 = 0, 1, 2, 3
 
 EXPORTS = [
     "fn2_strerror", "fn2_abi_version", "fn2_correlation_output_shape",

@@ -188,6 +188,7 @@ def test_correlation_golden(dev, path):
 
 
 MFMA_CASES = [  # B, C, H, W, md  (k=1, s1=1, s2=2, pad=md)
+    (2, 64, 12, 16, 20), (1, 32, 10, 40, 12), (1, 96, 14, 20, 8), (1, 64, 6, 64, 16), (2, 32, 48, 64, 20),
     (1, 32, 6, 8, 20), (2, 16, 8, 8, 20), (1, 64, 16, 24, 20), (1, 16, 10, 40, 20), (1, 16, 8, 130, 20),
     (1, 32, 12, 16, 4), (2, 16, 10, 12, 6), (1, 16, 6, 6, 2), (1, 48, 14, 18, 10), (1, 16, 20, 72, 14),
     (1, 16, 8, 8, 21),
@@ -211,6 +212,15 @@ def test_correlation_mfma_vs_oracle(dev, oracle, case):
     assert max_abs(o, ref) <= TOL
     assert max_abs(direct.cpu().numpy(), ref) <= TOL
     assert max_abs(o, ref) <= 2e-6, "fp32 MFMA chain should agree with the fp32 oracle to rounding"
+    # the auto path (bf16x3 exact-split kernel where it applies) and the explicit bf16x3 selector
+    auto = torch.full_like(out, float("nan"))
+    fn2_capi.correlation_forward(ad, bd, md, 1, md, 1, 2, algo=fn2_capi.FN2_CORR_AUTO, out=auto)
+    assert np.isfinite(auto.cpu().numpy()).all()
+    assert max_abs(auto.cpu().numpy(), ref) <= 2e-6
+    if W <= 64 and C % 32 == 0 and (md // 2) % 2 == 0 and W % 4 == 0:
+        b3 = torch.full_like(out, float("nan"))
+        fn2_capi.correlation_forward(ad, bd, md, 1, md, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_BF16X3, out=b3)
+        assert np.isfinite(b3.cpu().numpy()).all() and max_abs(b3.cpu().numpy(), ref) <= 2e-6
 
 
 BWD_CASES = [  # B, C, H, W, md  (k=1, s1=1, s2=2, pad=md); C % 32 == 0
@@ -257,6 +267,31 @@ def test_correlation_full_size_vs_oracle(dev, oracle, dist):
         assert max_abs(out[sl], ref) <= TOL
         r1, r2 = oracle.corr_bwd(a[sl].numpy(), b[sl].numpy(), go[sl].numpy(), *params)
         assert max_abs(g1[sl], r1) <= TOL and max_abs(g2[sl], r2) <= TOL
+
+
+def test_correlation_bf16x3_accuracy_vs_fp64(dev):
+    """The exact-split bf16 kernel is fp32-class: against an fp64 reference its error is no worse than the fp32
+    MFMA kernel's, for unit-scale, large, small and wide-dynamic-range inputs (scale-invariant)."""
+    import fn2_capi
+    import torch.nn.functional as F
+    B, C, H, W = 2, 256, 48, 64
+    g = torch.Generator().manual_seed(21)
+
+    def ref64(x1, x2):
+        p2 = F.pad(x2.double(), (20, 20, 20, 20))
+        outs = [(x1.double() * p2[:, :, 20 + 2 * tj:20 + 2 * tj + H, 20 + 2 * ti:20 + 2 * ti + W]).mean(1, keepdim=True)
+                for tj in range(-10, 11) for ti in range(-10, 11)]
+        return torch.cat(outs, 1)
+
+    for scale, spread in [(1.0, 0.0), (100.0, 0.0), (1e-3, 0.0), (1.0, 3.0)]:
+        x1 = (scale * torch.randn(B, C, H, W, generator=g) * torch.exp(spread * torch.randn(B, C, H, W, generator=g))).to(dev)
+        x2 = (scale * torch.randn(B, C, H, W, generator=g) * torch.exp(spread * torch.randn(B, C, H, W, generator=g))).to(dev)
+        r = ref64(x1, x2)
+        e32 = float((fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F32).double() - r).abs().max())
+        e3 = float((fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_BF16X3).double() - r).abs().max())
+        tol = 3e-6 * float(r.abs().max())
+        assert e3 <= tol and e32 <= tol, (scale, spread, e3, e32, tol)
+        assert e3 <= 3.0 * e32 + 1e-30, (scale, spread, e3, e32)
 
 
 def test_correlation_full_size_properties(dev):
