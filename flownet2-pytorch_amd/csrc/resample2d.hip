@@ -189,111 +189,258 @@ __global__ __launch_bounds__(256) void resample_bwd_kernel(const float *__restri
     }
 }
 
-// ---------------------------------------------------------------- backward, LDS-privatised scatter
-// Device-scope fp32 atomics to scattered addresses leave the XCD (the per-XCD L2s are not coherent)
-// and run at a few tens of G atomics/s.  Here a workgroup owns a TH x TW tile of SOURCE pixels and
-// accumulates their four-corner contributions into an LDS window covering the tile +- R pixels with
-// LDS atomics; only targets outside the window (|flow| > R) go to global memory one by one.  The
-// window is then flushed as contiguous rows (64 lanes = 256 B of consecutive addresses per atomic
-// instruction, exact zeros skipped), because the windows of neighbouring tiles overlap.
-// grad_flow is formed exactly as in resample_bwd_kernel (same operation order).
-template <int TH, int TW, int R, int CC>
-__global__ __launch_bounds__(512) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
-                                                         const float *__restrict__ flow,
-                                                         const float *__restrict__ gout,
-                                                         float *__restrict__ gimg, float *__restrict__ gflow,
-                                                         int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y)
+// ---------------------------------------------------------------- tiled kernels (LDS windows)
+// With an arbitrary flow every lane of a wave gathers from / scatters to a different cache line; the per-CU
+// vector-memory path then moves a 64-128 B line per 4 useful bytes, and device-scope fp32 atomics to scattered
+// addresses leave the XCD (the per-XCD L2s are not coherent) at a few tens of G atomics/s.  The tiled kernels
+// give a workgroup a TH x TW tile of output / source pixels and an LDS window covering the tile +- R pixels:
+//   forward : the image window is loaded with coalesced 16 B loads, one channel at a time, and the four
+//             bilinear corners are gathered from LDS; samples whose corners leave the window read global memory
+//   backward: per channel, an image window (for the flow gradient's corner differences) and an accumulation
+//             window: the four-corner scatter goes to LDS (compare-and-swap adds), only out-of-window targets use global
+//             atomics, and the window is flushed as contiguous rows (exact zeros skipped) -- the windows of
+//             neighbouring tiles overlap, so the flush accumulates too.
+// Arithmetic and operation order are those of the reference kernels (see resample_fwd_kernel /
+// resample_bwd_kernel above, which remain as the fallback for small images and strided pixel layouts).
+// fp32 accumulation into LDS.  The native ds_add_f32 runs at ~0.33 lane-atomics/clk/CU on gfx950 (measured,
+// scripts/ubench/lds_atomics.hip: integer LDS atomics reach 7-11), a compare-and-swap loop on the same word
+// reaches ~2.5 -- 7x faster for the scattered, rarely colliding adds of the warp gradient.
+__device__ __forceinline__ void lds_add_f32(float *addr, float v)
 {
-    constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1;   // +1: rows start on different banks
-    constexpr int NT = 512;                                         // threads per workgroup
-    constexpr int PPT = TH * TW / NT;                               // source pixels per thread
-    __shared__ float win[CC * WH * WWP];
+    unsigned *a = reinterpret_cast<unsigned *>(addr);
+    unsigned old = *a, assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+    } while (old != assumed);
+}
+
+template <int TH, int TW, int R>
+__global__ __launch_bounds__(512) void resample_fwd_tiled(const float *__restrict__ img, ImgStrides is,
+                                                         const float *__restrict__ flow, float *__restrict__ out,
+                                                         int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
+                                                         int bilinear)
+{
+    constexpr int NT = 512, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT;
+    __shared__ __attribute__((aligned(16))) float win[WH * WW];
 
     const int tid = threadIdx.x;
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int X0 = tx * TW, Y0 = ty * TH;
-    const int wx0 = X0 - R, wy0 = Y0 - R;
-    const long HW = (long)H * W, HWi = (long)Hi * Wi;
+    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const long HW = (long)H * W;
 
-    float out_dx[PPT], out_dy[PPT];
+    // per-pixel sampling state, formed once and reused for every channel
+    int o00[PPT], o01[PPT], o10[PPT], o11[PPT];     // window offsets (in-window) or image offsets (not)
+    double w00[PPT], w01[PPT], w10[PPT], w11[PPT];
+    bool inwin[PPT], live[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) out_dx[k] = out_dy[k] = 0.0f;
-
-    for (int c0 = 0; c0 < C; c0 += CC) {
-        const int nc = min(CC, C - c0);
-        for (int i = tid; i < CC * WH * WWP; i += NT) win[i] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int idx = tid + NT * k;
-            const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            if (x >= W || y >= H) continue;
-            const long p = (long)y * W + x;
-            const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
-            const float xf = (float)x + dx, yf = (float)y + dy;
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        live[k] = (x < W) && (y < H);
+        o00[k] = o01[k] = o10[k] = o11[k] = 0;
+        w00[k] = w01[k] = w10[k] = w11[k] = 0.;
+        inwin[k] = true;
+        if (!live[k]) continue;
+        const long p = (long)y * W + x;
+        const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        int xL, xR, yT, yB;
+        if (bilinear) {
             const float fx = floorf(xf), fy = floorf(yf);
-            const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
-            const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);   // (:105-106)
-            const int sxL = clampi(ixL, 0, Wi - 1), sxR = clampi(ixR, 0, Wi - 1);          // (:108-114)
-            const int syT = clampi(iyT, 0, Hi - 1), syB = clampi(iyB, 0, Hi - 1);
-            const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta);
-            const float s10 = (1 - alpha) * beta, s11 = alpha * beta;
-            // all four corners lie in [sxL, sxR] x [syT, syB]: one window test per pixel
-            const int lxL = sxL - wx0, lxR = sxR - wx0, lyT = syT - wy0, lyB = syB - wy0;
-            const bool inwin = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
-            const int gxL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), gxR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
-            const int gyT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), gyB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
-            const float gam_y = 1 - (xf - fx), gam_x = 1 - (yf - fy);
-            for (int cc = 0; cc < nc; ++cc) {
-                const int ch = c0 + cc;
-                const float go = gout[((long)b * C + ch) * HW + p];
-                if (inwin) {
-                    float *Wc = win + cc * (WH * WWP);
-                    atomicAdd(Wc + lyT * WWP + lxL, s00 * go);   // ds_add_f32
-                    atomicAdd(Wc + lyT * WWP + lxR, s01 * go);
-                    atomicAdd(Wc + lyB * WWP + lxL, s10 * go);
-                    atomicAdd(Wc + lyB * WWP + lxR, s11 * go);
-                } else {
-                    float *G = gimg + ((long)b * C + ch) * HWi;
-                    unsafeAtomicAdd(G + (long)syT * Wi + sxL, s00 * go);
-                    unsafeAtomicAdd(G + (long)syT * Wi + sxR, s01 * go);
-                    unsafeAtomicAdd(G + (long)syB * Wi + sxL, s10 * go);
-                    unsafeAtomicAdd(G + (long)syB * Wi + sxR, s11 * go);
-                }
-                const float *I = img + (long)b * is.b + (long)ch * is.c;
-                const float iTL = I[gyT * is.h + gxL * is.w], iTR = I[gyT * is.h + gxR * is.w];
-                const float iBL = I[gyB * is.h + gxL * is.w], iBR = I[gyB * is.h + gxR * is.w];
-                out_dy[k] = out_dy[k] + (gam_y * go) * iBL;       // (:172-177)
-                out_dy[k] = out_dy[k] - (gam_y * go) * iTL;
-                out_dy[k] = out_dy[k] + ((1 - gam_y) * go) * iBR;
-                out_dy[k] = out_dy[k] - ((1 - gam_y) * go) * iTR;
-                out_dx[k] = out_dx[k] + (gam_x * go) * iTR;       // (:185-190)
-                out_dx[k] = out_dx[k] - (gam_x * go) * iTL;
-                out_dx[k] = out_dx[k] + ((1 - gam_x) * go) * iBR;
-                out_dx[k] = out_dx[k] - ((1 - gam_x) * go) * iBL;
+            const float alpha = xf - fx, beta = yf - fy;               // (:45-46)
+            xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1);     // clamped with the OUTPUT dims (:49-52)
+            xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
+            yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1);
+            yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
+            const double a = (double)alpha, be = (double)beta;         // "1." literals -> double (:56-59)
+            w00[k] = (1. - a) * (1. - be);
+            w01[k] = a * (1. - be);
+            w10[k] = (1. - a) * be;
+            w11[k] = a * be;
+        } else {
+            xL = xR = clampi(clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), 0, Wi - 1);   // (:66-67)
+            yT = yB = clampi(clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1), 0, Hi - 1);
+            w00[k] = 1.;
+        }
+        const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+        inwin[k] = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+        if (inwin[k]) {
+            o00[k] = lyT * WW + lxL; o01[k] = lyT * WW + lxR; o10[k] = lyB * WW + lxL; o11[k] = lyB * WW + lxR;
+        } else {
+            o00[k] = yT * (int)is.h + xL * (int)is.w; o01[k] = yT * (int)is.h + xR * (int)is.w;
+            o10[k] = yB * (int)is.h + xL * (int)is.w; o11[k] = yB * (int)is.h + xR * (int)is.w;
+        }
+    }
+
+    for (int c = 0; c < C; ++c) {
+        const float *I = img + (long)b * is.b + (long)c * is.c;
+        // window rows are contiguous in the image (pixel stride 1 is a launcher precondition): 16 B per lane
+        for (int i = tid; i < WH * (WW / 4); i += NT) {
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            if (gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi)
+                *reinterpret_cast<f4 *>(win + ly * WW + lx) = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
+            else if (gy >= 0 && gy < Hi) {
+                for (int e = 0; e < 4; ++e)
+                    if (gx + e >= 0 && gx + e < Wi) win[ly * WW + lx + e] = I[(long)gy * is.h + gx + e];
             }
         }
         __syncthreads();
-        // flush: window rows are contiguous in grad_img
-        for (int i = tid; i < nc * WH * WW; i += NT) {
-            const int lx = i % WW;
-            const int r = i / WW;
-            const int ly = r % WH, cc = r / WH;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (!live[k]) continue;
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            float i00, i01, i10, i11;
+            if (inwin[k]) { i00 = win[o00[k]]; i01 = win[o01[k]]; i10 = win[o10[k]]; i11 = win[o11[k]]; }
+            else { i00 = I[o00[k]]; i01 = I[o01[k]]; i10 = I[o10[k]]; i11 = I[o11[k]]; }
+            float val;
+            if (bilinear) {
+                val = 0.0f;
+                val = val + (float)(w00[k] * (double)i00);
+                val = val + (float)(w01[k] * (double)i01);
+                val = val + (float)(w10[k] * (double)i10);
+                val = val + (float)(w11[k] * (double)i11);
+            } else {
+                val = i00;
+            }
+            out[((long)b * C + c) * HW + (long)y * W + x] = val;
+        }
+        __syncthreads();
+    }
+}
+
+template <int TH, int TW, int R>
+__global__ __launch_bounds__(1024) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
+                                                         const float *__restrict__ flow,
+                                                         const float *__restrict__ gout,
+                                                         float *__restrict__ gimg, float *__restrict__ gflow,
+                                                         int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
+                                                         int abl)   // abl: profiling switches (0 in production)
+{
+    constexpr int NT = 1024, WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT;
+    __shared__ __attribute__((aligned(16))) float iwin[WH * WW];   // image window
+    __shared__ float awin[WH * WWP];                               // accumulation window (+1: rows on different banks)
+
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const long HW = (long)H * W, HWi = (long)Hi * Wi;
+
+    // per-pixel state (flow is read once)
+    float s00[PPT], s01[PPT], s10[PPT], s11[PPT], gam_x[PPT], gam_y[PPT], out_dx[PPT], out_dy[PPT];
+    int sc[PPT][4];      // scatter targets: window offsets (in-window) or image offsets
+    int gc[PPT][4];      // gather corners TL, TR, BL, BR: window offsets or image offsets
+    bool s_in[PPT], g_in[PPT], live[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        live[k] = (x < W) && (y < H);
+        out_dx[k] = out_dy[k] = 0.0f;
+        s00[k] = s01[k] = s10[k] = s11[k] = gam_x[k] = gam_y[k] = 0.0f;
+        s_in[k] = g_in[k] = true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[k][e] = gc[k][e] = 0;
+        if (!live[k]) continue;
+        const long p = (long)y * W + x;
+        const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float fx = floorf(xf), fy = floorf(yf);
+        const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
+        const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);   // truncation (:105-106)
+        s00[k] = (1 - alpha) * (1 - beta); s01[k] = alpha * (1 - beta);
+        s10[k] = (1 - alpha) * beta;       s11[k] = alpha * beta;
+        gam_y[k] = 1 - (xf - fx);   // c == 1 branch (:169)
+        gam_x[k] = 1 - (yf - fy);   // c == 0 branch (:182)
+        {   // scatter corners: clamped with the INPUT1 dims (:108-114)
+            const int xL = clampi(ixL, 0, Wi - 1), xR = clampi(ixR, 0, Wi - 1);
+            const int yT = clampi(iyT, 0, Hi - 1), yB = clampi(iyB, 0, Hi - 1);
+            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+            s_in[k] = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            if (s_in[k]) { sc[k][0] = lyT * WWP + lxL; sc[k][1] = lyT * WWP + lxR; sc[k][2] = lyB * WWP + lxL; sc[k][3] = lyB * WWP + lxR; }
+            else { sc[k][0] = yT * Wi + xL; sc[k][1] = yT * Wi + xR; sc[k][2] = yB * Wi + xL; sc[k][3] = yB * Wi + xR; }
+        }
+        {   // gather corners: clamped with the FLOW dims (:163-166), then to the image
+            const int xL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), xR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
+            const int yT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), yB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
+            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+            g_in[k] = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            if (g_in[k]) { gc[k][0] = lyT * WW + lxL; gc[k][1] = lyT * WW + lxR; gc[k][2] = lyB * WW + lxL; gc[k][3] = lyB * WW + lxR; }
+            else {
+                gc[k][0] = yT * (int)is.h + xL * (int)is.w; gc[k][1] = yT * (int)is.h + xR * (int)is.w;
+                gc[k][2] = yB * (int)is.h + xL * (int)is.w; gc[k][3] = yB * (int)is.h + xR * (int)is.w;
+            }
+        }
+    }
+
+    for (int c = 0; c < C; ++c) {
+        const float *I = img + (long)b * is.b + (long)c * is.c;
+        float *G = gimg + ((long)b * C + c) * HWi;
+        for (int i = tid; i < WH * WWP; i += NT) awin[i] = 0.0f;
+        for (int i = tid; i < WH * (WW / 4); i += NT) {
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            if (gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi)
+                *reinterpret_cast<f4 *>(iwin + ly * WW + lx) = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
+            else if (gy >= 0 && gy < Hi) {
+                for (int e = 0; e < 4; ++e)
+                    if (gx + e >= 0 && gx + e < Wi) iwin[ly * WW + lx + e] = I[(long)gy * is.h + gx + e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (!live[k]) continue;
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            const float go = gout[((long)b * C + c) * HW + (long)y * W + x];
+            if (abl & 2) {
+            } else if (s_in[k]) {
+                lds_add_f32(awin + sc[k][0], s00[k] * go);
+                lds_add_f32(awin + sc[k][1], s01[k] * go);
+                lds_add_f32(awin + sc[k][2], s10[k] * go);
+                lds_add_f32(awin + sc[k][3], s11[k] * go);
+            } else {
+                unsafeAtomicAdd(G + sc[k][0], s00[k] * go);
+                unsafeAtomicAdd(G + sc[k][1], s01[k] * go);
+                unsafeAtomicAdd(G + sc[k][2], s10[k] * go);
+                unsafeAtomicAdd(G + sc[k][3], s11[k] * go);
+            }
+            float iTL, iTR, iBL, iBR;
+            if (abl & 4) { iTL = iTR = iBL = iBR = go; }
+            else if (g_in[k]) { iTL = iwin[gc[k][0]]; iTR = iwin[gc[k][1]]; iBL = iwin[gc[k][2]]; iBR = iwin[gc[k][3]]; }
+            else { iTL = I[gc[k][0]]; iTR = I[gc[k][1]]; iBL = I[gc[k][2]]; iBR = I[gc[k][3]]; }
+            out_dy[k] = out_dy[k] + (gam_y[k] * go) * iBL;       // (:172-177)
+            out_dy[k] = out_dy[k] - (gam_y[k] * go) * iTL;
+            out_dy[k] = out_dy[k] + ((1 - gam_y[k]) * go) * iBR;
+            out_dy[k] = out_dy[k] - ((1 - gam_y[k]) * go) * iTR;
+            out_dx[k] = out_dx[k] + (gam_x[k] * go) * iTR;       // (:185-190)
+            out_dx[k] = out_dx[k] - (gam_x[k] * go) * iTL;
+            out_dx[k] = out_dx[k] + ((1 - gam_x[k]) * go) * iBR;
+            out_dx[k] = out_dx[k] - ((1 - gam_x[k]) * go) * iBL;
+        }
+        __syncthreads();
+        for (int i = tid; i < WH * WW; i += NT) {
+            const int ly = i / WW, lx = i - ly * WW;
             const int gx = wx0 + lx, gy = wy0 + ly;
-            const float v = win[cc * (WH * WWP) + ly * WWP + lx];
-            if (v != 0.0f && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi)
-                unsafeAtomicAdd(gimg + ((long)b * C + c0 + cc) * HWi + (long)gy * Wi + gx, v);
+            const float v = awin[ly * WWP + lx];
+            if (!(abl & 1) && v != 0.0f && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) unsafeAtomicAdd(G + (long)gy * Wi + gx, v);
         }
         __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
+        if (!live[k]) continue;
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        if (x >= W || y >= H) continue;
         const long p = (long)y * W + x;
         gflow[(long)b * 2 * HW + p] = out_dx[k];
         gflow[(long)b * 2 * HW + HW + p] = out_dy[k];
@@ -326,13 +473,23 @@ extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strid
     else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long npix = (long)B * H * W;
+    // tiled path: image rows contiguous and 16 B aligned, same size as the flow, large enough to tile
+    const bool tiled_ok = (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && aligned(img, 16) &&
+                          (Hi == H) && (Wi == W) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
+    if (tiled_ok) {
+        constexpr int TH = 32, TW = 64;
+        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+        hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(512), 0, s,
+                           img, is, flow, out, C, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);
+        return launch_status();
+    }
     if (W % 4 == 0 && aligned(flow, 16) && aligned(out, 16)) {
         const long ng = npix / 4;
         hipLaunchKernelGGL(resample_fwd_kernel<4>, dim3(stream_grid(ng)), dim3(256), 0, s, img, is, flow, out, C, Hi, Wi,
-                           H, W, ng, bilinear ? 1 : 0);
+                           H, W, ng, (bilinear & 1) ? 1 : 0);
     } else {
         hipLaunchKernelGGL(resample_fwd_kernel<1>, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, out, C, Hi,
-                           Wi, H, W, npix, bilinear ? 1 : 0);
+                           Wi, H, W, npix, (bilinear & 1) ? 1 : 0);
     }
     return launch_status();
 }
@@ -356,11 +513,14 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
     else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long npix = (long)B * H * W;
-    if (H >= 16 && W >= 32 && !(bilinear & 0x100)) {
+    const bool tiled_ok = (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && aligned(img, 16) &&
+                          (Hi == H) && (Wi == W) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
+    if (tiled_ok) {
         constexpr int TH = 32, TW = 64;
         const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, 16, 3>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(512),
-                           0, s, img, is, flow, grad_out, grad_img, grad_flow, C, Hi, Wi, H, W, tiles_x, tiles_y);
+        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024),
+                           0, s, img, is, flow, grad_out, grad_img, grad_flow, C, Hi, Wi, H, W, tiles_x, tiles_y,
+                           (bilinear >> 9) & 7);   // bits 9-11 of `bilinear`: profiling switches, 0 from the bindings
     } else {
         hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out,
                            grad_img, grad_flow, C, Hi, Wi, H, W, npix);

@@ -1,0 +1,37 @@
+"""Micro-benchmark of the resample2d kernels through the C ABI (bilinear flag bits 8.. select profiling variants)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
+import torch, fn2_capi
+lib = fn2_capi.lib()
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+B, C, H, W = 8, 3, 384, 512
+img = (torch.rand(B, C, H, W, generator=g) - 0.5).to(dev)
+flow = torch.randn(B, 2, H, W, generator=g) * 4.0
+idx = torch.randint(0, flow.numel(), (flow.numel() // 100,), generator=g)
+flow.view(-1)[idx] *= 20.0
+smooth = torch.nn.functional.avg_pool2d(torch.randn(B, 2, H, W, generator=g) * 30, 31, 1, 15).to(dev)
+gout = torch.randn(B, C, H, W, generator=g).to(dev)
+out = torch.zeros_like(img); gimg = torch.zeros_like(img); gflow = torch.zeros(B, 2, H, W, device=dev)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    ev = []
+    for _ in range(n):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); ev.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
+    return ts[len(ts) // 2]
+for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth)):
+    print(name)
+    for flags, lab in ((1, "fwd tiled"), (1 | 0x100, "fwd untiled")):
+        t = timeit(lambda: lib.fn2_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, flags, st))
+        print("   %-28s %.1f us" % (lab, t))
+    for flags, lab in ((1, "bwd tiled"), (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
+                       (1 | 0xE00, "bwd tiled, none of them"), (1 | 0x100, "bwd untiled")):
+        t = timeit(lambda: lib.fn2_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, flags, st))
+        print("   %-28s %.1f us" % (lab, t))
