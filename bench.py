@@ -245,7 +245,7 @@ def main():
                 "sharding": "batch over ranks, no data-path collective",
             },
             "roofline": {
-                "kernel": "correlation forward (corr_fwd_mfma_f32)",
+                "kernel": "correlation forward (corr_fwd_mfma_bf16x3)",
                 "bound": "hbm",
                 "achieved": cf["achieved_GBps"],
                 "peak": HBM_PEAK_GBS,
