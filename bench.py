@@ -244,6 +244,10 @@ def main():
                 "pairs_per_step_per_gpu": CORR["B"],
                 "sharding": "batch over ranks, no data-path collective",
             },
+            "configs1_correlation_only": {   # BASELINE.json configs[1]: correlation layer alone, fwd+bwd, 8x256x48x64 fp32
+                "ms_fwd_bwd": round(kernels["corr_fwd"]["ms"] + kernels["corr_bwd"]["ms"], 5),
+                "image_pairs_per_s_per_gpu": round(CORR["B"] / ((kernels["corr_fwd"]["ms"] + kernels["corr_bwd"]["ms"]) * 1e-3), 1),
+            },
             "roofline": {
                 "kernel": "correlation forward (corr_fwd_mfma_bf16x3)",
                 "bound": "hbm",

@@ -653,10 +653,11 @@ __device__ __forceinline__ void split3(const float (&r)[8], u4 &t0, u4 &t1, u4 &
     }
 }
 
-template <int NV, int EP, int VAR>
-__global__ __launch_bounds__(512, 2) void corr_fwd_mfma_bf16x3(Args p)
+// NST = 2: two-stage ring, one workgroup per CU (133 KB).  NST = 1: one stage (66 KB, two-pass epilogue), two
+// workgroups per CU -- the other workgroup's vector work covers this one's DMA latency and store drain.
+template <int NV, int EP, int VAR, int NST = 2>
+__global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(Args p)
 {
-    constexpr int NST = 2;
     constexpr int O_FLOATS = (16 / EP) * (2 * DR_MAX + 1) * O_RS + 64;
     constexpr int LDS_FLOATS = (NST * SB_STAGE > O_FLOATS) ? NST * SB_STAGE : O_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
@@ -793,9 +794,18 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_mfma_bf16x3(Args p)
             wait_all_but(0);
             __builtin_amdgcn_s_barrier();   // step sk is visible to all; the other stage is free
             const bool more = (sk + 1 < nsteps);
-            if (more && early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
-            mma_step(sk & 1);
-            if (more && !early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
+            if (NST == 2) {
+                if (more && early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
+                mma_step(sk & 1);
+                if (more && !early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
+            } else {
+                mma_step(0);
+                if (more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // every wave has read the stage: refill it
+                    dma_issue((sk + 1) * SB_CK, 0);
+                }
+            }
         }
         __syncthreads();
     }
@@ -888,6 +898,10 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
         case 2000: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2001: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2002: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 2>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2100: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 0, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2101: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 1, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2004: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 4>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2007: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 7>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 1100: FN2_WS(8, 4, 2, 0, 4)     // 4 loader waves, 4 stages of 8 channels (86 KB)
         case 1101: FN2_WS(8, 4, 2, 1, 4)
         case 1108: FN2_WS(8, 4, 2, 8, 4)
@@ -906,7 +920,7 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
     if (tune == 3 && !bf16x3_ok) return FN2_EUNSUPPORTED;
     if ((tune == 0 || tune == 3) && bf16x3_ok) {
         switch (a.NV) {
-#define FN2_B3(NVV) case NVV: hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<NVV, 1, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+#define FN2_B3(NVV) case NVV: hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<NVV, 2, 0, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();   // one stage, two workgroups per CU
             FN2_B3(2) FN2_B3(3) FN2_B3(4) FN2_B3(5) FN2_B3(6)
 #undef FN2_B3
         default: return FN2_EUNSUPPORTED;

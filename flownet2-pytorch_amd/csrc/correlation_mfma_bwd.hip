@@ -297,7 +297,7 @@ bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k
     return C % 32 == 0;
 }
 
-// tune: 0 = shipped configuration (64-channel groups when C % 64 == 0, else 32); 1 = force 32-channel groups
+// tune: 0 = shipped configuration (64- or 32-channel groups, see below); 1 = force 32-channel groups; 2 = force 64
 int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,
                            int B, int C, int H, int W, int md, int tune, hipStream_t s)
 {
@@ -310,9 +310,15 @@ int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout
     const int NV = 1 + (a.dr + 1) / 2;
     a.NRG = (H / 2 + 3) / 4;
     a.NXT = (W + mb::TILE_X - 1) / mb::TILE_X;
-    const bool g64 = (C % 64 == 0) && tune != 1;
+    // 64-channel groups stage the G tile half as often as 32-channel groups, but the grid must also fill the
+    // 256 CUs (one workgroup each) in whole rounds: pick the group size with the better last-round occupancy,
+    // preferring 64 when they are close.
+    const long base = (long)B * 2 * a.NRG * a.NXT;
+    auto round_eff = [](long t) { const long r = (t + 255) / 256; return r ? (double)t / (double)(r * 256) : 1.0; };
+    bool g64 = (C % 64 == 0) && tune != 1;   // tune 2: 64 where possible, no occupancy heuristic
+    if (g64 && tune == 0 && round_eff(base * (C / 32)) > 1.1 * round_eff(base * (C / 64))) g64 = false;
     a.NCG = C / (g64 ? 64 : 32);
-    const long ntasks = (long)B * 2 * a.NRG * a.NXT * a.NCG;
+    const long ntasks = base * a.NCG;
     if (ntasks == 0) return FN2_OK;
     int rc;
     a.nbr = in2; a.gin = g1;
