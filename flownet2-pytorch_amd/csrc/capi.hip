@@ -21,11 +21,6 @@ extern "C" const char *fn2_strerror(int code)
 
 extern "C" int fn2_abi_version(void) { return FN2_ABI_VERSION; }
 
-// Profiling hook, not part of the public ABI (not declared in flownet2_hip.h): device buffer for the
-// s_memtime stamps of the instrumented kernel instantiations.
-namespace fn2 { void corr_set_debug_buffer(void *p); }
-extern "C" void fn2_debug_set_buffer(void *p) { fn2::corr_set_debug_buffer(p); }
-
 // correlation_cuda.cc:19-34
 extern "C" int fn2_correlation_output_shape(int H, int W, int pad_size, int kernel_size, int max_displacement,
                                             int stride1, int stride2, int *nOut, int *oH, int *oW)

@@ -59,7 +59,6 @@ struct Args {
     int C, H, W;     // H, W even
     int dr, D, NV;   // displacement radius (lattice), 2dr+1, B blocks per A block per axis
     int NRG, NXT;    // row groups per parity, x tiles
-    unsigned long long *dbg;   // profiling only: s_memtime stamps (VAR bit 8 of the DMA kernel), else null
 };
 
 // Tunables of one instantiation.
@@ -81,13 +80,10 @@ struct Cfg {
 // D layout of v_mfma_f32_16x16x4_f32: lane l, register r holds D[row = 4*(l>>4) + r][col = l&15];
 // rows are A pixels (ai = row>>2 = l>>4, aj = row&3 = r), columns B pixels (bi = fi>>2, bj = fi&3).
 // The caller guarantees that every wave has finished reading the operand buffers that alias `smem`.
-template <int NV, int EP, int VAR, int NW = 8>
+template <int NV, int EP, int VAR>
 __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Args &p, int lane, int wave, int n,
                                          int py, int rg, int u, int X0, int HL, long HW)
 {
-    // waves 0..7 hold accumulators; any further waves (loader waves of the specialised kernel) only help
-    // with the write-out
-    const bool holds_acc = (NW == 8) || (wave < 8);
     const int xpar = wave & 1;
     const int a0 = (wave >> 1) << 1;
     const int fi = lane & 15, fq = lane >> 4;
@@ -105,7 +101,7 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
         const int xg = X0 + 2 * hx;
 #pragma unroll
         for (int pass = 0; pass < EP; ++pass) {
-            const bool mine = holds_acc && ((EP == 1) || ((e_ai / AI_PER_PASS) == pass));
+            const bool mine = (EP == 1) || ((e_ai / AI_PER_PASS) == pass);
             const int plane = ((e_ai % AI_PER_PASS) * 4 + e_bi) * p.D;
 #pragma unroll
             for (int ab = 0; ab < 2; ++ab)
@@ -124,7 +120,7 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
             __syncthreads();
             // each wave writes whole planes: rows (plane, ti) for ti = 0..D-1, two rows per instruction,
             // 8 B per lane -> one 256 B contiguous segment per row
-            for (int pl = wave; pl < 4 * AI_PER_PASS; pl += NW) {
+            for (int pl = wave; pl < 4 * AI_PER_PASS; pl += 8) {
                 const int ai = pass * AI_PER_PASS + (pl >> 2), bi = pl & 3;
                 const int tj = 4 * u + bi - ai;
                 const int IL = 4 * rg + ai;
@@ -147,12 +143,12 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
     }
 }
 
-template <int NV, int CK, int NBUF, int EP, int WPS, int VAR, bool X4, bool DMAX = false>
+template <int NV, int CK, int NBUF, int EP, int WPS, int VAR, bool X4>
 __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
 {
     typedef Cfg<CK, NBUF, EP> G;
     static_assert(CK % 8 == 0 && (CK * 4) % 8 == 0, "staging assigns whole rows to waves");
-    __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS + (DMAX ? 8192 : 0)];   // DMAX: + 32 KB DMA sink
+    __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,20 +205,6 @@ __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
     auto stage_load = [&](int c0) {
         if (VAR & 2) return;
         if (VAR & 16) c0 = 0;   // profiling: every chunk re-reads chunk 0 (always L2-resident)
-        if (DMAX) {             // profiling: the chunk's bytes arrive by LDS-DMA into a sink region instead
-            // wave w: 4 instructions of 1 KB: rows (4 per instruction) x 16 pieces of 16 B
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = lane >> 4, piece = lane & 15;
-                const int ch = c0 + 2 * wave + (k >> 1);
-                const float *base = (k & 1) ? in2n : in1n;
-                int il = (k & 1) ? (ib0 + row) : (4 * rg + row);
-                il = il < 0 ? 0 : (il >= HL ? HL - 1 : il);
-                const float *g = base + (long)ch * HW + (long)(2 * il + py) * p.W + 4 * piece;
-                float *l = smem + G::LDS_FLOATS + wave * 1024 + k * 256;
-                __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-            }
-        }
         if (VAR & 32) {         // profiling: no global loads (the LDS writes still happen)
 #pragma unroll
             for (int k = 0; k < KB; ++k) rb[k] = (ld_t)(1.0f);
@@ -253,7 +235,6 @@ __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_f32(Args p)
             return;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (DMAX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float *As = smem + buf * G::BUF_FLOATS;
         float *Bs = As + G::A_FLOATS;
         if (!(VAR & 32)) {   // zero the lanes that loaded the dummy address
@@ -401,19 +382,14 @@ struct DCfg {
     static constexpr int LDS_FLOATS = (NST * ST_FLOATS > O_FLOATS) ? NST * ST_FLOATS : O_FLOATS;
 };
 
-// NLD = 0: every wave stages its share of a chunk and computes (8 waves).
-// NLD > 0: wave specialisation -- waves 0..7 only read operands and issue MFMAs, waves 8..8+NLD-1 only issue
-// the DMAs.  A CU's memory pipeline accepts VMEM instructions at roughly 11-19 B/clk and issue is in order,
-// so a wave that stages its own data sits in VMEM issue for 1000-1800 clocks per chunk with its MFMAs
-// queued behind; loader waves absorb that stall while the matrix pipe keeps running.
-template <int NV, int CK, int NST, int EP, int WPS, int VAR, int NLD = 0>
-__global__ __launch_bounds__(512 + 64 * NLD, (NLD ? (8 + NLD + 3) / 4 : WPS)) void corr_fwd_mfma_dma(Args p)
+// (Dedicated loader waves -- 4 extra waves that only issue the DMAs -- were measured too: slower, because the
+// fp32 MFMA blocks vector-memory issue on its SIMD whichever wave issues it)
+template <int NV, int CK, int NST, int EP, int WPS, int VAR>
+__global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_dma(Args p)
 {
     typedef DCfg<CK, NST, EP> G;
-    constexpr int NLW = NLD ? NLD : 8;            // waves that issue DMAs
-    constexpr int NW = 8 + NLD;                   // waves in the workgroup
-    static_assert((CK * 3) % NLW == 0, "3 DMA instructions per channel are spread evenly over the loading waves");
-    constexpr int DPW = CK * 3 / NLW;   // DMA instructions per loading wave per chunk
+    static_assert((CK * 3) % 8 == 0, "3 DMA instructions per channel are spread evenly over the 8 waves");
+    constexpr int DPW = CK * 3 / 8;   // DMA instructions per wave per chunk
     __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -436,18 +412,15 @@ __global__ __launch_bounds__(512 + 64 * NLD, (NLD ? (8 + NLD + 3) / 4 : WPS)) vo
 
     // ---- DMA roles.  Instruction j (0 .. 3*CK-1) of a chunk: channel j/3, kind j%3
     //   kind 0: B pieces 0..63   kind 1: B pieces 64..103 (lanes 0..39)   kind 2: the A rows
-    // loading wave lw issues instructions lw*DPW .. lw*DPW+DPW-1.  Per-lane source offsets (within a channel
+    // wave w issues instructions w*DPW .. w*DPW+DPW-1.  Per-lane source offsets (within a channel
     // plane) and validity do not depend on the chunk.
-    const bool is_loader = NLD ? (wave >= 8) : true;
-    const bool is_consumer = NLD ? (wave < 8) : true;
-    const int lw = NLD ? (wave >= 8 ? wave - 8 : 0) : wave;
     int d_off[DPW];     // element offset inside the channel plane, or -1
     int d_ch[DPW];      // channel within the chunk
     int d_lds[DPW];     // LDS float offset of the instruction's 1 KB window inside a stage
     bool d_isA[DPW];
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
-        const int j = lw * DPW + k;
+        const int j = wave * DPW + k;
         const int ch = j / 3, kind = j % 3;
         d_ch[k] = ch;
         d_isA[k] = (kind == 2);
@@ -490,7 +463,7 @@ __global__ __launch_bounds__(512 + 64 * NLD, (NLD ? (8 + NLD + 3) / 4 : WPS)) vo
         }
     };
     auto dma_issue = [&](int c0, int stage) {
-        if ((VAR & 2) || !is_loader) return;
+        if (VAR & 2) return;
         float *st = smem + stage * G::ST_FLOATS;
 #pragma unroll
         for (int k = 0; k < DPW; ++k) {
@@ -553,37 +526,24 @@ __global__ __launch_bounds__(512 + 64 * NLD, (NLD ? (8 + NLD + 3) / 4 : WPS)) vo
     const int nchunks = all_pad ? 0 : p.C / CK;
     if (nchunks > 0) {
         // zero the ring once: positions outside the image are never written by the DMA
-        for (int i = tid; i < NST * G::ST_FLOATS / 4; i += 64 * NW) reinterpret_cast<f4 *>(smem)[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = tid; i < NST * G::ST_FLOATS / 4; i += 512) reinterpret_cast<f4 *>(smem)[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
         // prologue: NST-1 chunks in flight
 #pragma unroll
         for (int c = 0; c < NST - 1; ++c)
             if (c < nchunks) dma_issue(c * CK, c);
-        // profiling (VAR & 8): wave 0 of two fixed interior tasks records s_memtime at 5 points of every chunk
-        const bool task_a = (n == 0 && py == 0 && rg == 2 && u == 2), task_b = (n == 3 && py == 1 && rg == 3 && u == 3);
-        const bool stamp = (VAR & 8) && p.dbg && wave == 0 && (task_a || task_b);
-        unsigned long long *dbg = p.dbg ? p.dbg + (task_a ? 0 : 1024) : nullptr;
-#define FN2_STAMP(i) if ((VAR & 8) && stamp && lane == 0) dbg[ck * 8 + (i)] = __builtin_amdgcn_s_memtime();
         for (int ck = 0; ck < nchunks; ++ck) {
-            FN2_STAMP(0)
             // chunk ck has landed once at most the DMAs of the (NST-2) younger chunks are outstanding; the
             // tail (fewer younger chunks issued) simply drains everything.
-            if (is_loader) {
-                if (ck + NST - 2 < nchunks) wait_younger(NST - 2);
-                else wait_younger(0);
-            }
-            FN2_STAMP(1)
+            if (ck + NST - 2 < nchunks) wait_younger(NST - 2);
+            else wait_younger(0);
             __builtin_amdgcn_s_barrier();   // every wave's share of chunk ck is visible; stage (ck-1)%NST is free
-            FN2_STAMP(2)
             if (ck + NST - 1 < nchunks) dma_issue((ck + NST - 1) * CK, (ck + NST - 1) % NST);
-            FN2_STAMP(3)
-            if (is_consumer) mma_chunk(ck % NST);
-            FN2_STAMP(4)
+            mma_chunk(ck % NST);
         }
-#undef FN2_STAMP
         __syncthreads();   // all operand reads done before the epilogue reuses the ring
     }
-    epilogue<NV, EP, VAR, NW>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
+    epilogue<NV, EP, VAR>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -853,10 +813,6 @@ static int launch_nv(const Args &a, long ntasks, hipStream_t s)
 
 } // namespace mf
 
-static unsigned long long *g_corr_dbg = nullptr;   // profiling only (fn2_debug_set_buffer); never set in production
-void corr_set_debug_buffer(void *p) { g_corr_dbg = static_cast<unsigned long long *>(p); }
-
-// tune: 0 = shipped configuration; 100 + 256*cfg + var = profiling instantiations (NV = 6 only)
 // tune: 0 = fastest applicable kernel (bf16x3 split where it applies, else fp32 MFMA); 2 = fp32 MFMA only
 //       (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain); 3 = bf16x3 only; >= 100 profiling instantiations
 int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
@@ -864,7 +820,6 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
 {
     if (!aligned(in1, 8) || !aligned(in2, 8)) return FN2_EALIGN;
     mf::Args a;
-    a.dbg = g_corr_dbg;
     a.in1 = in1; a.in2 = in2; a.out = out;
     a.C = C; a.H = H; a.W = W;
     a.dr = md / 2; a.D = 2 * a.dr + 1; a.NV = 1 + (a.dr + 1) / 2;
@@ -879,10 +834,6 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
 #define FN2_DMA(CK, NST, EP, WPS, V)                                                                             \
     hipLaunchKernelGGL((mf::corr_fwd_mfma_dma<6, CK, NST, EP, WPS, V>), dim3((unsigned)ntasks), dim3(512), 0, s, a); \
     return launch_status();
-#define FN2_WS(CK, NST, EP, V, NLD)                                                                              \
-    hipLaunchKernelGGL((mf::corr_fwd_mfma_dma<6, CK, NST, EP, 2, V, NLD>), dim3((unsigned)ntasks),               \
-                       dim3(512 + 64 * NLD), 0, s, a);                                                           \
-    return launch_status();
         switch (tune) {
         case 1000: FN2_DMA(8, 3, 2, 4, 0)
         case 1001: FN2_DMA(8, 3, 2, 4, 1)
@@ -892,9 +843,6 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
         case 1020: FN2_DMA(8, 4, 2, 2, 0)
         case 1030: FN2_DMA(16, 2, 1, 2, 0)
         case 1040: FN2_DMA(8, 2, 2, 4, 0)
-        case 1008: FN2_DMA(8, 3, 2, 4, 8)
-        case 1009: FN2_DMA(8, 3, 2, 4, 9)
-        case 1038: FN2_DMA(16, 2, 1, 2, 8)
         case 2000: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2001: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2002: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 2>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
@@ -902,17 +850,9 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
         case 2101: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 1, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2004: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 4>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2007: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 7>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
-        case 1100: FN2_WS(8, 4, 2, 0, 4)     // 4 loader waves, 4 stages of 8 channels (86 KB)
-        case 1101: FN2_WS(8, 4, 2, 1, 4)
-        case 1108: FN2_WS(8, 4, 2, 8, 4)
-        case 1110: FN2_WS(16, 3, 1, 0, 4)    // 4 loader waves, 3 stages of 16 channels (130 KB)
-        case 1120: FN2_WS(8, 3, 2, 0, 4)     // 65 KB: two workgroups per CU
-        case 1130: FN2_WS(8, 4, 2, 0, 2)     // 2 loader waves
-        case 1140: FN2_WS(16, 3, 1, 0, 2)
         default: return FN2_EUNSUPPORTED;
         }
 #undef FN2_DMA
-#undef FN2_WS
     }
     // bf16x3: exact 3-way operand split on the bf16 matrix cores (fp32-class accuracy, see kernel comment);
     // needs the whole width in one x tile, 32-channel steps and 4-pixel aligned rows
@@ -944,10 +884,6 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B,
         FN2_V(CK, NBUF, EP, WPS, 37) FN2_V(CK, NBUF, EP, WPS, 64) FN2_V(CK, NBUF, EP, WPS, 65)                \
         FN2_V(CK, NBUF, EP, WPS, 69) FN2_V(CK, NBUF, EP, WPS, 128)                                            \
     default: return FN2_EUNSUPPORTED;                                                                         \
-    }
-    if (cfg == 2) {   // LDS-DMA cost experiment: cfg 1 with constant operands + the chunk bytes DMA'd into a sink
-        hipLaunchKernelGGL((mf::corr_fwd_mfma_f32<6, 16, 1, 2, 4, 32, true, true>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
-        return launch_status();
     }
     switch (cfg) {
     case 0: FN2_VARS(16, 2, 1, 2)   // 94 KB LDS, 1 workgroup / CU
