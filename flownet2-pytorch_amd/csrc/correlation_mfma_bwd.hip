@@ -50,15 +50,20 @@ typedef float __attribute__((ext_vector_type(4))) f4;
 typedef float __attribute__((ext_vector_type(2))) f2;
 
 struct Args {
-    const float *nbr;    // in2 (FLIP = 0) or in1 (FLIP = 1)
+    const float *nbr[2];   // [0] = in2 (neighbours of gradInput1), [1] = in1 (neighbours of gradInput2)
     const float *gout;
-    float *gin;          // gradInput1 (FLIP = 0) or gradInput2 (FLIP = 1)
+    float *gin[2];         // [0] = gradInput1 (FLIP = 0), [1] = gradInput2 (FLIP = 1)
     int C, H, W;
     int dr, D;
     int NRG, NXT, NCG;
+    int nflip;             // 2: both gradients in this launch (task id's top factor), 1: only `flip0`
+    int flip0;
 };
 
-template <int NV, int NCT, int FLIP>
+// Both gradients run in ONE launch (FLIP is the slowest-varying factor of the task id): at the FlowNetC shape a
+// gradient has 384 tasks = 1.5 rounds of 256 single-workgroup CUs, the two together 768 = exactly 3 rounds.
+// VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no neighbour staging, 4 no G staging, 8 no stores
+template <int NV, int NCT, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
 {
     constexpr int CG = NCT * CK;
@@ -76,14 +81,16 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
     const int cg = (int)(t % p.NCG); t /= p.NCG;
     const int xt = (int)(t % p.NXT); t /= p.NXT;
     const int rg = (int)(t % p.NRG); t /= p.NRG;
-    const int py = (int)(t & 1u);
-    const int n = (int)(t >> 1);
+    const int py = (int)(t & 1u); t >>= 1;
+    const int nb = (int)gridDim.x / (p.nflip * 2 * p.NRG * p.NXT * p.NCG);   // batch size
+    const int n = (int)(t % nb);
+    const int FLIP = __builtin_amdgcn_readfirstlane(p.nflip == 2 ? (int)(t / nb) : p.flip0);
 
     const int HL = p.H >> 1;
     const long HW = (long)p.H * p.W;
     const int X0 = xt * TILE_X;
     const int c_base = cg * CG;
-    const float *nbr_n = p.nbr + ((long)n * p.C + c_base) * HW;
+    const float *nbr_n = p.nbr[FLIP] + ((long)n * p.C + c_base) * HW;
     const float *go_n = p.gout + (long)n * p.D * p.D * HW;
 
     // ---- neighbour-tile staging roles (as the forward's B tile): wave w stages row bi = w&3 of
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
 
     f2 rn[8];
     auto nbr_load = [&](int u, int ct) {
+        if (VAR & 2) return;
         const int il = 4 * rg - p.dr + 4 * u + s_bi;     // neighbour lattice row
         const bool ok = s_col_ok && (il >= 0) && (il < HL);
         const float *src = ok ? nbr_n + (long)(ct * CK + (wave >> 2)) * HW + (long)(2 * il + py) * p.W + s_xb : nbr_n;
@@ -106,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
         }
     };
     auto nbr_write = [&](int buf) {
+        if (VAR & 2) return;
         float *N = Ns + buf * N_FLOATS;
         if (s_jb < B_COLS) {
 #pragma unroll
@@ -120,11 +129,14 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
     // lane = (row-in-pair hr, x pair hx): one float2 per lane, two rows per instruction.
     const int hx = lane & 31, hr = lane >> 5;
     auto g_stage = [&](int u) {
+        if (VAR & 4) return;
         constexpr int NP = (2 * DR_MAX + 1 + 1) / 2;   // ti pairs
         const int HWi = p.H * p.W;                     // 32-bit offsets: D*D*H*W < 2^31 (checked by the launcher)
+        // all 2 x NP loads are issued before the first LDS write: at this point of the u loop the 48 G-fragment
+        // registers of the previous u are dead, so the registers are free and the load latency is paid once
+        f2 rg_[2][NP];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f2 rg_[NP];
             const int pl = wave + 8 * h;
             const int ai = pl >> 2, bi = pl & 3;
             const int tj = 4 * u + bi - ai;          // displacement row index of this plane
@@ -152,13 +164,18 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
                     const int x = X0 + 2 * hx + 2 * (ti - p.dr);
                     ok = ok && (x >= 0) && (x < p.W);
                 }
-                f2 v = *reinterpret_cast<const f2 *>(go_n + (ok ? base + i * step : 0));
-                rg_[i] = ok ? v : (f2){0.0f, 0.0f};
+                f2 v = (f2){0.0f, 0.0f};
+                if (ok) v = *reinterpret_cast<const f2 *>(go_n + (base + i * step));
+                rg_[h][i] = v;
             }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pl = wave + 8 * h;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int ti = 2 * i + hr;
-                if (ti < p.D) *reinterpret_cast<f2 *>(Gs + (pl * p.D + ti) * G_RS + 2 * hx) = rg_[i];
+                if (ti < p.D) *reinterpret_cast<f2 *>(Gs + (pl * p.D + ti) * G_RS + 2 * hx) = rg_[h][i];
             }
         }
     };
@@ -227,7 +244,8 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
                     for (int v = 0; v < NV; ++v)
 #pragma unroll
                         for (int ab = 0; ab < 2; ++ab)
-                            acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfr[ab][v][s], nf[cur][ab + v], acc[ab][ct], 0, 0, 0);
+                            if (VAR & 1) asm volatile("" ::"v"(gfr[ab][v][s]), "v"(nf[cur][ab + v]));
+                            else acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfr[ab][v][s], nf[cur][ab + v], acc[ab][ct], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (more) nbr_write(buf ^ 1);
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
         const bool pow2 = (p.C & (p.C - 1)) == 0;
         const float rC = 1.0f / fC;
         const int xg = X0 + lane;
-        float *gin_n = p.gin + ((long)n * p.C + c_base) * HW;
+        float *gin_n = p.gin[FLIP] + ((long)n * p.C + c_base) * HW;
         for (int R = wave; R < CG * 4; R += 8) {
             const int ch = R >> 2, ai = R & 3;
             const int IL = 4 * rg + ai;
@@ -263,28 +281,28 @@ __global__ __launch_bounds__(512, 2) void corr_bwd_mfma_f32(Args p)
             if (xg < p.W) {
                 float val = Es[R * E_RS + lane];
                 val = pow2 ? val * rC : val / fC;    // sum / nelems (correlation_cuda_kernel.cu:238,:331)
-                gin_n[(long)ch * HW + (long)(2 * IL + py) * p.W + xg] = val;
+                if (!(VAR & 8)) gin_n[(long)ch * HW + (long)(2 * IL + py) * p.W + xg] = val;
             }
         }
     }
 }
 
-template <int NV, int NCT, int FLIP>
+template <int NV, int NCT>
 static int launch(const Args &a, long ntasks, hipStream_t s)
 {
-    hipLaunchKernelGGL((corr_bwd_mfma_f32<NV, NCT, FLIP>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((corr_bwd_mfma_f32<NV, NCT>), dim3((unsigned)ntasks), dim3(512), 0, s, a);
     return launch_status();
 }
 
-template <int NCT, int FLIP>
+template <int NCT>
 static int launch_nv(int NV, const Args &a, long ntasks, hipStream_t s)
 {
     switch (NV) {
-    case 2: return launch<2, NCT, FLIP>(a, ntasks, s);
-    case 3: return launch<3, NCT, FLIP>(a, ntasks, s);
-    case 4: return launch<4, NCT, FLIP>(a, ntasks, s);
-    case 5: return launch<5, NCT, FLIP>(a, ntasks, s);
-    case 6: return launch<6, NCT, FLIP>(a, ntasks, s);
+    case 2: return launch<2, NCT>(a, ntasks, s);
+    case 3: return launch<3, NCT>(a, ntasks, s);
+    case 4: return launch<4, NCT>(a, ntasks, s);
+    case 5: return launch<5, NCT>(a, ntasks, s);
+    case 6: return launch<6, NCT>(a, ntasks, s);
     default: return FN2_EUNSUPPORTED;
     }
 }
@@ -297,7 +315,8 @@ bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k
     return C % 32 == 0;
 }
 
-// tune: 0 = shipped configuration (64- or 32-channel groups, see below); 1 = force 32-channel groups; 2 = force 64
+// tune: 0 = shipped configuration (both gradients in one launch; 64- or 32-channel groups, see below);
+//       1 = force 32-channel groups; 2 = force 64; 3 = one launch per gradient
 int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,
                            int B, int C, int H, int W, int md, int tune, hipStream_t s)
 {
@@ -312,21 +331,37 @@ int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout
     a.NXT = (W + mb::TILE_X - 1) / mb::TILE_X;
     // 64-channel groups stage the G tile half as often as 32-channel groups, but the grid must also fill the
     // 256 CUs (one workgroup each) in whole rounds: pick the group size with the better last-round occupancy,
-    // preferring 64 when they are close.
-    const long base = (long)B * 2 * a.NRG * a.NXT;
+    // preferring 64 when they are close.  tune 3: one launch per gradient (A/B against the fused launch).
+    const bool fused = (tune != 3);   // tune 10 + v: profiling variant v of the fused launch
+    const long base = (long)B * 2 * a.NRG * a.NXT * (fused ? 2 : 1);
     auto round_eff = [](long t) { const long r = (t + 255) / 256; return r ? (double)t / (double)(r * 256) : 1.0; };
     bool g64 = (C % 64 == 0) && tune != 1;   // tune 2: 64 where possible, no occupancy heuristic
-    if (g64 && tune == 0 && round_eff(base * (C / 32)) > 1.1 * round_eff(base * (C / 64))) g64 = false;
+    if (g64 && (tune == 0 || tune == 3) && round_eff(base * (C / 32)) > 1.1 * round_eff(base * (C / 64))) g64 = false;
     a.NCG = C / (g64 ? 64 : 32);
     const long ntasks = base * a.NCG;
     if (ntasks == 0) return FN2_OK;
-    int rc;
-    a.nbr = in2; a.gin = g1;
-    rc = g64 ? mb::launch_nv<4, 0>(NV, a, ntasks, s) : mb::launch_nv<2, 0>(NV, a, ntasks, s);
-    if (rc != FN2_OK) return rc;
-    a.nbr = in1; a.gin = g2;
-    rc = g64 ? mb::launch_nv<4, 1>(NV, a, ntasks, s) : mb::launch_nv<2, 1>(NV, a, ntasks, s);
-    return rc;
+    a.nbr[0] = in2; a.gin[0] = g1;
+    a.nbr[1] = in1; a.gin[1] = g2;
+    if (tune >= 10 && tune < 26 && NV == 6 && g64) {   // profiling instantiations (FlowNetC radius only)
+        a.nflip = 2; a.flip0 = 0;
+        switch (tune - 10) {
+#define FN2_BV(V) case V: hipLaunchKernelGGL((mb::corr_bwd_mfma_f32<6, 4, V>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+            FN2_BV(1) FN2_BV(2) FN2_BV(4) FN2_BV(6) FN2_BV(7) FN2_BV(8) FN2_BV(15)
+#undef FN2_BV
+        default: return FN2_EUNSUPPORTED;
+        }
+    }
+    if (fused) {
+        a.nflip = 2; a.flip0 = 0;
+        return g64 ? mb::launch_nv<4>(NV, a, ntasks, s) : mb::launch_nv<2>(NV, a, ntasks, s);
+    }
+    a.nflip = 1;
+    for (int f = 0; f < 2; ++f) {
+        a.flip0 = f;
+        const int rc = g64 ? mb::launch_nv<4>(NV, a, ntasks, s) : mb::launch_nv<2>(NV, a, ntasks, s);
+        if (rc != FN2_OK) return rc;
+    }
+    return FN2_OK;
 }
 
 } // namespace fn2
