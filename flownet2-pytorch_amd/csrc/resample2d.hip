@@ -216,13 +216,18 @@ __device__ __forceinline__ void lds_add_f32(float *addr, float v)
 }
 
 template <int TH, int TW, int R>
-__global__ __launch_bounds__(512) void resample_fwd_tiled(const float *__restrict__ img, ImgStrides is,
-                                                         const float *__restrict__ flow, float *__restrict__ out,
-                                                         int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
-                                                         int bilinear)
+__global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__restrict__ img, ImgStrides is,
+                                                            const float *__restrict__ flow, float *__restrict__ out,
+                                                            int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
+                                                            int bilinear)
 {
-    constexpr int NT = 512, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT;
-    __shared__ __attribute__((aligned(16))) float win[WH * WW];
+    // 1024 threads, <= 64 VGPRs: two workgroups (32 waves) per CU.  Per-pixel state is 4 registers: the four corners are
+    // base + {0, dx, dy*stride, both} (clamping can only merge neighbours) and the double-precision weights are rebuilt per
+    // channel from alpha/beta with the reference's expressions.  The window is double-buffered: channel c+1 is loaded to
+    // registers before channel c is gathered and written to the other buffer afterwards -- one barrier per channel.
+    constexpr int NT = 1024, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT;
+    __shared__ __attribute__((aligned(16))) float win[2][WH * WW];
+    enum { LIVE = 1, IN_WIN = 2, DX = 4, DY = 8 };
 
     const int tid = threadIdx.x;
     int t = blockIdx.x;
@@ -232,99 +237,115 @@ __global__ __launch_bounds__(512) void resample_fwd_tiled(const float *__restric
     const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
     const long HW = (long)H * W;
 
-    // per-pixel sampling state, formed once and reused for every channel
-    int o00[PPT], o01[PPT], o10[PPT], o11[PPT];     // window offsets (in-window) or image offsets (not)
-    double w00[PPT], w01[PPT], w10[PPT], w11[PPT];
-    bool inwin[PPT], live[PPT];
+    float alpha[PPT], beta[PPT];
+    int base[PPT], flags[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        live[k] = (x < W) && (y < H);
-        o00[k] = o01[k] = o10[k] = o11[k] = 0;
-        w00[k] = w01[k] = w10[k] = w11[k] = 0.;
-        inwin[k] = true;
-        if (!live[k]) continue;
+        alpha[k] = beta[k] = 0.0f;
+        base[k] = flags[k] = 0;
+        if (!((x < W) && (y < H))) continue;
         const long p = (long)y * W + x;
         const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
         const float xf = (float)x + dx, yf = (float)y + dy;
         int xL, xR, yT, yB;
         if (bilinear) {
             const float fx = floorf(xf), fy = floorf(yf);
-            const float alpha = xf - fx, beta = yf - fy;               // (:45-46)
+            alpha[k] = xf - fx; beta[k] = yf - fy;                     // (:45-46)
             xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1);     // clamped with the OUTPUT dims (:49-52)
             xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
             yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1);
             yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
-            const double a = (double)alpha, be = (double)beta;         // "1." literals -> double (:56-59)
-            w00[k] = (1. - a) * (1. - be);
-            w01[k] = a * (1. - be);
-            w10[k] = (1. - a) * be;
-            w11[k] = a * be;
         } else {
             xL = xR = clampi(clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), 0, Wi - 1);   // (:66-67)
             yT = yB = clampi(clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1), 0, Hi - 1);
-            w00[k] = 1.;
         }
         const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-        inwin[k] = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
-        if (inwin[k]) {
-            o00[k] = lyT * WW + lxL; o01[k] = lyT * WW + lxR; o10[k] = lyB * WW + lxL; o11[k] = lyB * WW + lxR;
-        } else {
-            o00[k] = yT * (int)is.h + xL * (int)is.w; o01[k] = yT * (int)is.h + xR * (int)is.w;
-            o10[k] = yB * (int)is.h + xL * (int)is.w; o11[k] = yB * (int)is.h + xR * (int)is.w;
-        }
+        const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+        base[k] = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
+        flags[k] = LIVE | (in ? IN_WIN : 0) | (xR != xL ? DX : 0) | (yB != yT ? DY : 0);
     }
+
+    // window rows are contiguous in the image (pixel stride 1 and Wi % 4 == 0 are launcher preconditions): 16 B per
+    // lane, a 4-px group is entirely inside or outside the image
+    constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
+    f4 wreg[NW];
+    auto win_load = [&](const float *I) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int i = tid + NT * j;
+            asm volatile("" : "+v"(i));    // keep the address arithmetic inside the channel loop (register budget)
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                v = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
+            wreg[j] = v;
+        }
+    };
+    auto win_write = [&](float *dst) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(dst + 4 * i) = wreg[j];
+        }
+    };
+    if (C > 0) { win_load(img + (long)b * is.b); win_write(win[0]); }
+    __syncthreads();
 
     for (int c = 0; c < C; ++c) {
         const float *I = img + (long)b * is.b + (long)c * is.c;
-        // window rows are contiguous in the image (pixel stride 1 is a launcher precondition): 16 B per lane
-        for (int i = tid; i < WH * (WW / 4); i += NT) {
-            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
-            const int gy = wy0 + ly, gx = wx0 + lx;
-            if (gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi)
-                *reinterpret_cast<f4 *>(win + ly * WW + lx) = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
-            else if (gy >= 0 && gy < Hi) {
-                for (int e = 0; e < 4; ++e)
-                    if (gx + e >= 0 && gx + e < Wi) win[ly * WW + lx + e] = I[(long)gy * is.h + gx + e];
-            }
-        }
-        __syncthreads();
+        const float *wc = win[c & 1];
+        if (c + 1 < C) win_load(I + is.c);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            if (!live[k]) continue;
-            const int idx = tid + NT * k;
+            int fl = flags[k], o = base[k], idx = tid + NT * k;
+            if (!(fl & LIVE)) continue;
+            asm volatile("" : "+v"(fl), "+v"(o), "+v"(idx));   // as above
             const int x = X0 + idx % TW, y = Y0 + idx / TW;
             float i00, i01, i10, i11;
-            if (inwin[k]) { i00 = win[o00[k]]; i01 = win[o01[k]]; i10 = win[o10[k]]; i11 = win[o11[k]]; }
-            else { i00 = I[o00[k]]; i01 = I[o01[k]]; i10 = I[o10[k]]; i11 = I[o11[k]]; }
+            if (fl & IN_WIN) {
+                const int ox = (fl & DX) ? 1 : 0, oy = (fl & DY) ? WW : 0;
+                i00 = wc[o]; i01 = wc[o + ox]; i10 = wc[o + oy]; i11 = wc[o + oy + ox];
+            } else {
+                const int ox = (fl & DX) ? (int)is.w : 0, oy = (fl & DY) ? (int)is.h : 0;
+                i00 = I[o]; i01 = I[o + ox]; i10 = I[o + oy]; i11 = I[o + oy + ox];
+            }
             float val;
             if (bilinear) {
+                const double a = (double)alpha[k], be = (double)beta[k];   // "1." literals -> double (:56-59)
                 val = 0.0f;
-                val = val + (float)(w00[k] * (double)i00);
-                val = val + (float)(w01[k] * (double)i01);
-                val = val + (float)(w10[k] * (double)i10);
-                val = val + (float)(w11[k] * (double)i11);
+                val = val + (float)(((1. - a) * (1. - be)) * (double)i00);
+                val = val + (float)((a * (1. - be)) * (double)i01);
+                val = val + (float)(((1. - a) * be) * (double)i10);
+                val = val + (float)((a * be) * (double)i11);
             } else {
                 val = i00;
             }
-            out[((long)b * C + c) * HW + (long)y * W + x] = val;
+            out[((long)b * C + c) * HW + (y * W + x)] = val;
         }
+        if (c + 1 < C) win_write(win[(c + 1) & 1]);
         __syncthreads();
     }
 }
 
-template <int TH, int TW, int R>
-__global__ __launch_bounds__(1024) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
-                                                         const float *__restrict__ flow,
-                                                         const float *__restrict__ gout,
-                                                         float *__restrict__ gimg, float *__restrict__ gflow,
-                                                         int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
-                                                         int abl)   // abl: profiling switches (0 in production)
+template <int TH, int TW, int R, int NT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
+                                                            const float *__restrict__ flow,
+                                                            const float *__restrict__ gout,
+                                                            float *__restrict__ gimg, float *__restrict__ gflow,
+                                                            int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
+                                                            int abl)   // abl: profiling switches (0 in production)
 {
-    constexpr int NT = 1024, WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT;
+    // Two workgroups per CU (<= 64 VGPRs, 2 x 49 KB LDS): one workgroup's window loads overlap the other's LDS scatter.
+    // Per-pixel state is therefore kept small: the four corners are base + {0, dx, dy*stride, both} with dx, dy in {0,1}
+    // (clamping can only merge neighbours), and the bilinear weights are recomputed per channel from alpha/beta with the
+    // reference's expressions.
+    constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT;
     __shared__ __attribute__((aligned(16))) float iwin[WH * WW];   // image window
     __shared__ float awin[WH * WWP];                               // accumulation window (+1: rows on different banks)
+    enum { LIVE = 1, S_IN = 2, G_IN = 4, S_DX = 8, S_DY = 16, G_DX = 32, G_DY = 64 };
 
     const int tid = threadIdx.x;
     int t = blockIdx.x;
@@ -335,89 +356,114 @@ __global__ __launch_bounds__(1024) void resample_bwd_tiled(const float *__restri
     const long HW = (long)H * W, HWi = (long)Hi * Wi;
 
     // per-pixel state (flow is read once)
-    float s00[PPT], s01[PPT], s10[PPT], s11[PPT], gam_x[PPT], gam_y[PPT], out_dx[PPT], out_dy[PPT];
-    int sc[PPT][4];      // scatter targets: window offsets (in-window) or image offsets
-    int gc[PPT][4];      // gather corners TL, TR, BL, BR: window offsets or image offsets
-    bool s_in[PPT], g_in[PPT], live[PPT];
+    float alpha[PPT], beta[PPT], gam_x[PPT], gam_y[PPT], out_dx[PPT], out_dy[PPT];
+    int sbase[PPT], gbase[PPT], flags[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        live[k] = (x < W) && (y < H);
         out_dx[k] = out_dy[k] = 0.0f;
-        s00[k] = s01[k] = s10[k] = s11[k] = gam_x[k] = gam_y[k] = 0.0f;
-        s_in[k] = g_in[k] = true;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sc[k][e] = gc[k][e] = 0;
-        if (!live[k]) continue;
+        alpha[k] = beta[k] = gam_x[k] = gam_y[k] = 0.0f;
+        sbase[k] = gbase[k] = 0;
+        flags[k] = 0;
+        if (!((x < W) && (y < H))) continue;
+        int fl = LIVE;
         const long p = (long)y * W + x;
         const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
         const float xf = (float)x + dx, yf = (float)y + dy;
         const float fx = floorf(xf), fy = floorf(yf);
         const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
-        const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);   // truncation (:105-106)
-        s00[k] = (1 - alpha) * (1 - beta); s01[k] = alpha * (1 - beta);
-        s10[k] = (1 - alpha) * beta;       s11[k] = alpha * beta;
+        alpha[k] = xf - (float)f2i_sat(xf); beta[k] = yf - (float)f2i_sat(yf);   // truncation (:105-106)
         gam_y[k] = 1 - (xf - fx);   // c == 1 branch (:169)
         gam_x[k] = 1 - (yf - fy);   // c == 0 branch (:182)
         {   // scatter corners: clamped with the INPUT1 dims (:108-114)
             const int xL = clampi(ixL, 0, Wi - 1), xR = clampi(ixR, 0, Wi - 1);
             const int yT = clampi(iyT, 0, Hi - 1), yB = clampi(iyB, 0, Hi - 1);
             const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-            s_in[k] = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
-            if (s_in[k]) { sc[k][0] = lyT * WWP + lxL; sc[k][1] = lyT * WWP + lxR; sc[k][2] = lyB * WWP + lxL; sc[k][3] = lyB * WWP + lxR; }
-            else { sc[k][0] = yT * Wi + xL; sc[k][1] = yT * Wi + xR; sc[k][2] = yB * Wi + xL; sc[k][3] = yB * Wi + xR; }
+            const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            sbase[k] = in ? lyT * WWP + lxL : yT * Wi + xL;
+            fl |= (in ? S_IN : 0) | (xR != xL ? S_DX : 0) | (yB != yT ? S_DY : 0);
         }
         {   // gather corners: clamped with the FLOW dims (:163-166), then to the image
             const int xL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), xR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
             const int yT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), yB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
             const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-            g_in[k] = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
-            if (g_in[k]) { gc[k][0] = lyT * WW + lxL; gc[k][1] = lyT * WW + lxR; gc[k][2] = lyB * WW + lxL; gc[k][3] = lyB * WW + lxR; }
-            else {
-                gc[k][0] = yT * (int)is.h + xL * (int)is.w; gc[k][1] = yT * (int)is.h + xR * (int)is.w;
-                gc[k][2] = yB * (int)is.h + xL * (int)is.w; gc[k][3] = yB * (int)is.h + xR * (int)is.w;
-            }
+            const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            gbase[k] = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
+            fl |= (in ? G_IN : 0) | (xR != xL ? G_DX : 0) | (yB != yT ? G_DY : 0);
         }
+        flags[k] = fl;
+        __builtin_amdgcn_sched_barrier(0);
     }
+
+    // image-window staging: a thread owns NW 4-px groups; loaded to registers (so the loads of channel c+1 are in flight
+    // while channel c's accumulation window is flushed), then written to LDS
+    constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
+    f4 wreg[NW];
+    auto win_load = [&](const float *I) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int i = tid + NT * j;
+            asm volatile("" : "+v"(i));    // keep the address arithmetic inside the channel loop (register budget)
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            // Wi % 4 == 0 (launcher): a 4-px group is entirely inside or outside the image
+            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                v = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
+            wreg[j] = v;
+        }
+    };
+    auto win_write = [&]() {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + 4 * i) = wreg[j];
+        }
+    };
+    if (C > 0) win_load(img + (long)b * is.b);
+    for (int i = tid; i < WH * WWP; i += NT) awin[i] = 0.0f;
+    win_write();
+    __syncthreads();
 
     for (int c = 0; c < C; ++c) {
         const float *I = img + (long)b * is.b + (long)c * is.c;
         float *G = gimg + ((long)b * C + c) * HWi;
-        for (int i = tid; i < WH * WWP; i += NT) awin[i] = 0.0f;
-        for (int i = tid; i < WH * (WW / 4); i += NT) {
-            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
-            const int gy = wy0 + ly, gx = wx0 + lx;
-            if (gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi)
-                *reinterpret_cast<f4 *>(iwin + ly * WW + lx) = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
-            else if (gy >= 0 && gy < Hi) {
-                for (int e = 0; e < 4; ++e)
-                    if (gx + e >= 0 && gx + e < Wi) iwin[ly * WW + lx + e] = I[(long)gy * is.h + gx + e];
-            }
-        }
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            if (!live[k]) continue;
-            const int idx = tid + NT * k;
+            int fl = flags[k], sb = sbase[k], gb = gbase[k];
+            if (!(fl & LIVE)) continue;
+            // opaque to the optimiser: otherwise every corner address of every pixel is hoisted out of the channel
+            // loop and the kernel no longer fits the 64 VGPRs two workgroups per CU need
+            int idx = tid + NT * k;
+            asm volatile("" : "+v"(fl), "+v"(sb), "+v"(gb), "+v"(idx));
             const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            const float go = gout[((long)b * C + c) * HW + (long)y * W + x];
+            const float go = gout[((long)b * C + c) * HW + (y * W + x)];
+            const float s00 = (1 - alpha[k]) * (1 - beta[k]), s01 = alpha[k] * (1 - beta[k]);
+            const float s10 = (1 - alpha[k]) * beta[k], s11 = alpha[k] * beta[k];
             if (abl & 2) {
-            } else if (s_in[k]) {
-                lds_add_f32(awin + sc[k][0], s00[k] * go);
-                lds_add_f32(awin + sc[k][1], s01[k] * go);
-                lds_add_f32(awin + sc[k][2], s10[k] * go);
-                lds_add_f32(awin + sc[k][3], s11[k] * go);
+            } else if (fl & S_IN) {
+                const int ox = (fl & S_DX) ? 1 : 0, oy = (fl & S_DY) ? WWP : 0;
+                lds_add_f32(awin + sb, s00 * go);
+                lds_add_f32(awin + sb + ox, s01 * go);
+                lds_add_f32(awin + sb + oy, s10 * go);
+                lds_add_f32(awin + sb + oy + ox, s11 * go);
             } else {
-                unsafeAtomicAdd(G + sc[k][0], s00[k] * go);
-                unsafeAtomicAdd(G + sc[k][1], s01[k] * go);
-                unsafeAtomicAdd(G + sc[k][2], s10[k] * go);
-                unsafeAtomicAdd(G + sc[k][3], s11[k] * go);
+                const int ox = (fl & S_DX) ? 1 : 0, oy = (fl & S_DY) ? Wi : 0;
+                unsafeAtomicAdd(G + sb, s00 * go);
+                unsafeAtomicAdd(G + sb + ox, s01 * go);
+                unsafeAtomicAdd(G + sb + oy, s10 * go);
+                unsafeAtomicAdd(G + sb + oy + ox, s11 * go);
             }
             float iTL, iTR, iBL, iBR;
             if (abl & 4) { iTL = iTR = iBL = iBR = go; }
-            else if (g_in[k]) { iTL = iwin[gc[k][0]]; iTR = iwin[gc[k][1]]; iBL = iwin[gc[k][2]]; iBR = iwin[gc[k][3]]; }
-            else { iTL = I[gc[k][0]]; iTR = I[gc[k][1]]; iBL = I[gc[k][2]]; iBR = I[gc[k][3]]; }
+            else if (fl & G_IN) {
+                const int ox = (fl & G_DX) ? 1 : 0, oy = (fl & G_DY) ? WW : 0;
+                iTL = iwin[gb]; iTR = iwin[gb + ox]; iBL = iwin[gb + oy]; iBR = iwin[gb + oy + ox];
+            } else {
+                const int ox = (fl & G_DX) ? (int)is.w : 0, oy = (fl & G_DY) ? (int)is.h : 0;
+                iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
+            }
             out_dy[k] = out_dy[k] + (gam_y[k] * go) * iBL;       // (:172-177)
             out_dy[k] = out_dy[k] - (gam_y[k] * go) * iTL;
             out_dy[k] = out_dy[k] + ((1 - gam_y[k]) * go) * iBR;
@@ -426,25 +472,47 @@ __global__ __launch_bounds__(1024) void resample_bwd_tiled(const float *__restri
             out_dx[k] = out_dx[k] - (gam_x[k] * go) * iTL;
             out_dx[k] = out_dx[k] + ((1 - gam_x[k]) * go) * iBR;
             out_dx[k] = out_dx[k] - ((1 - gam_x[k]) * go) * iBL;
+            __builtin_amdgcn_sched_barrier(0);   // one pixel at a time: keeps the live set small
         }
         __syncthreads();
-        for (int i = tid; i < WH * WW; i += NT) {
-            const int ly = i / WW, lx = i - ly * WW;
-            const int gx = wx0 + lx, gy = wy0 + ly;
-            const float v = awin[ly * WWP + lx];
-            if (!(abl & 1) && v != 0.0f && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) unsafeAtomicAdd(G + (long)gy * Wi + gx, v);
+        if (c + 1 < C) win_load(I + is.c);
+        // flush the accumulation window as contiguous rows (exact zeros skipped) and clear it for the next channel
+        {
+            int ly = tid / WW, lx = tid - ly * WW;     // element tid, then steps of NT without divisions
+#pragma unroll 2
+            for (int i = tid; i < WH * WW; i += NT) {
+                const int gx = wx0 + lx, gy = wy0 + ly;
+                const float v = awin[ly * WWP + lx];
+                if (v != 0.0f) {
+                    awin[ly * WWP + lx] = 0.0f;
+                    if (!(abl & 1) && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) unsafeAtomicAdd(G + gy * Wi + gx, v);
+                }
+                ly += NT / WW; lx += NT % WW;
+                if (lx >= WW) { lx -= WW; ++ly; }
+            }
         }
+        if (c + 1 < C) win_write();
         __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        if (!live[k]) continue;
+        if (!(flags[k] & LIVE)) continue;
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
         const long p = (long)y * W + x;
         gflow[(long)b * 2 * HW + p] = out_dx[k];
         gflow[(long)b * 2 * HW + HW + p] = out_dy[k];
     }
+}
+
+// Tile height of the tiled kernels (two 1024-thread workgroups per CU = 512 resident tiles): the height that needs fewer
+// window rows over all rounds; 48 turns FlowNet2's 8 x 384 x 512 into exactly one round.
+static inline int tile_height(int B, int H, int tiles_x)
+{
+    const long slots = 512;
+    const long t32 = (long)B * tiles_x * ((H + 31) / 32), t48 = (long)B * tiles_x * ((H + 47) / 48);
+    const long c32 = ((t32 + slots - 1) / slots) * (32 + 32), c48 = ((t48 + slots - 1) / slots) * (48 + 32);
+    return c48 < c32 ? 48 : 32;
 }
 
 static inline unsigned stream_grid(long nthreads)
@@ -475,12 +543,19 @@ extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strid
     const long npix = (long)B * H * W;
     // tiled path: image rows contiguous and 16 B aligned, same size as the flow, large enough to tile
     const bool tiled_ok = (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && aligned(img, 16) &&
-                          (Hi == H) && (Wi == W) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
+                          (Hi == H) && (Wi == W) && (W % 4 == 0) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
     if (tiled_ok) {
-        constexpr int TH = 32, TW = 64;
-        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(512), 0, s,
-                           img, is, flow, out, C, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);
+        constexpr int TW = 64;
+        const int tiles_x = (W + TW - 1) / TW;
+#define FN2_RF(TH)                                                                                                     \
+    do {                                                                                                               \
+        const int tiles_y = (H + TH - 1) / TH;                                                                         \
+        hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024), \
+                           0, s, img, is, flow, out, C, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);       \
+    } while (0)
+        const int th = (bilinear >> 12) & 3 ? ((bilinear >> 12) & 3) == 1 ? 48 : 32 : tile_height(B, H, tiles_x);
+        if (th == 48) FN2_RF(48); else FN2_RF(32);
+#undef FN2_RF
         return launch_status();
     }
     if (W % 4 == 0 && aligned(flow, 16) && aligned(out, 16)) {
@@ -514,13 +589,25 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long npix = (long)B * H * W;
     const bool tiled_ok = (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && aligned(img, 16) &&
-                          (Hi == H) && (Wi == W) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
+                          (Hi == H) && (Wi == W) && (W % 4 == 0) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
     if (tiled_ok) {
-        constexpr int TH = 32, TW = 64;
-        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024),
-                           0, s, img, is, flow, grad_out, grad_img, grad_flow, C, Hi, Wi, H, W, tiles_x, tiles_y,
-                           (bilinear >> 9) & 7);   // bits 9-11 of `bilinear`: profiling switches, 0 from the bindings
+        constexpr int TW = 64;
+        const int abl = (bilinear >> 9) & 7;   // bits 9-11 of `bilinear`: profiling switches, 0 from the bindings
+        const int tiles_x = (W + TW - 1) / TW;
+#define FN2_RB(TH)                                                                                                     \
+    do {                                                                                                               \
+        const int tiles_y = (H + TH - 1) / TH;                                                                         \
+        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, 16, 1024, 8>), dim3((unsigned)((long)B * tiles_x * tiles_y)),   \
+                           dim3(1024), 0, s, img, is, flow, grad_out, grad_img, grad_flow, C, Hi, Wi, H, W, tiles_x,   \
+                           tiles_y, abl);                                                                              \
+    } while (0)
+        switch ((bilinear >> 12) & 3) {        // bits 12-13: tile height (profiling: 1 = 48, 2 = 32, 3 = 64), 0 = automatic
+        case 1: FN2_RB(48); break;
+        case 2: FN2_RB(32); break;
+        case 3: FN2_RB(64); break;
+        default: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48); else FN2_RB(32); break;
+        }
+#undef FN2_RB
     } else {
         hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out,
                            grad_img, grad_flow, C, Hi, Wi, H, W, npix);

@@ -28,10 +28,10 @@ def timeit(fn, n=20):
     return ts[len(ts) // 2]
 for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth)):
     print(name)
-    for flags, lab in ((1, "fwd tiled"), (1 | 0x100, "fwd untiled")):
+    for flags, lab in ((1, "fwd tiled"), (1 | 0x1000, "fwd tiled 48x64"), (1 | 0x2000, "fwd tiled 32x64"), (1 | 0x100, "fwd untiled")):
         t = timeit(lambda: lib.fn2_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, flags, st))
         print("   %-28s %.1f us" % (lab, t))
-    for flags, lab in ((1, "bwd tiled"), (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
+    for flags, lab in ((1, "bwd tiled"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"), (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
                        (1 | 0xE00, "bwd tiled, none of them"), (1 | 0x100, "bwd untiled")):
         t = timeit(lambda: lib.fn2_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, flags, st))
         print("   %-28s %.1f us" % (lab, t))
