@@ -99,13 +99,16 @@ extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, con
     const bool mfma_ok = corr_bwd_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                       stride2) &&
                          aligned(in1, 8) && aligned(in2, 8) && aligned(grad_out, 8);
-    if (algo == FN2_CORR_MFMA_BF16X3) return FN2_EUNSUPPORTED;   // forward only
-    if ((algo == FN2_CORR_MFMA_F32 || algo >= 100) && !mfma_ok) return FN2_EUNSUPPORTED;
-    if (algo == FN2_CORR_MFMA_F32 || algo >= 100 || (algo == FN2_CORR_AUTO && mfma_ok))
+    const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || algo >= 100);
+    if (wants_mfma && !mfma_ok) return FN2_EUNSUPPORTED;
+    if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok)) {
+        // internal tune: 0 = automatic (bf16x3 where its extra preconditions hold), 6 = fp32 MFMA, 4 = bf16x3 or
+        // FN2_EUNSUPPORTED, algo - 100 = profiling variants
+        const int tune = algo == FN2_CORR_MFMA_F32 ? 6 : algo == FN2_CORR_MFMA_BF16X3 ? 4 : algo >= 100 ? algo - 100 : 0;
         return corr_backward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
                                       static_cast<const float *>(grad_out), static_cast<float *>(grad_in1),
-                                      static_cast<float *>(grad_in2), B, C, H, W, max_displacement,
-                                      algo >= 100 ? algo - 100 : 0, s); // algo >= 100: profiling variants
+                                      static_cast<float *>(grad_in2), B, C, H, W, max_displacement, tune, s);
+    }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_backward_direct(in1, in2, grad_out, grad_in1, grad_in2, dtype, p, s);
 }

@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "corr_params.h"
+#include "bf16x3.h"
 
 namespace fn2 {
 
@@ -578,40 +579,12 @@ __global__ __launch_bounds__(512, WPS) void corr_fwd_mfma_dma(Args p)
 //
 // All 8 waves issue DMAs; waves 0-3 before their MFMA phase and waves 4-7 after it, so the two waves that
 // share a SIMD (w and w+4) are in complementary phases.
-typedef short __attribute__((ext_vector_type(8))) bf16x8;
-typedef unsigned __attribute__((ext_vector_type(4))) u4;
+// split helpers: bf16x3.h
 
 constexpr int SB_CH = 260;                 // channel stride (floats): 256 + 4 zero pad
 constexpr int SB_CK = 32;                  // channels per stage = per MFMA step
 constexpr int SB_TILE = SB_CK * SB_CH;     // floats per tile (A or B) per stage
 constexpr int SB_STAGE = 2 * SB_TILE;      // 16640 floats = 66 560 B
-
-__device__ __forceinline__ unsigned pack_hi16(float lo, float hi)
-{
-    // bf16(lo) in bits 0..15, bf16(hi) in bits 16..31 (both by truncation: the upper halves of the floats)
-    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
-
-// split 8 fp32 values into three packed bf16 operands (scalar subtractions: packed fp32 VALU next to MFMAs
-// measured slower on this kernel)
-__device__ __forceinline__ void split3(const float (&r)[8], u4 &t0, u4 &t1, u4 &t2)
-{
-    float h0[8], h1[8], h2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        h0[k] = trunc_bf16(r[k]);
-        const float r1 = r[k] - h0[k];   // exact
-        h1[k] = trunc_bf16(r1);
-        h2[k] = r1 - h1[k];              // exact, at most 8 significant bits
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        t0[m] = pack_hi16(h0[2 * m], h0[2 * m + 1]);
-        t1[m] = pack_hi16(h1[2 * m], h1[2 * m + 1]);
-        t2[m] = pack_hi16(h2[2 * m], h2[2 * m + 1]);
-    }
-}
 
 // NST = 2: two-stage ring, one workgroup per CU (133 KB).  NST = 1: one stage (66 KB, two-pass epilogue), two
 // workgroups per CU -- the other workgroup's vector work covers this one's DMA latency and store drain.

@@ -78,10 +78,10 @@ def correlation_forward(in1, in2, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=No
     return out
 
 
-def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO):
+def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=None):
     import torch
     B, C, H, W = in1.shape
-    g1, g2 = torch.empty_like(in1), torch.empty_like(in2)
+    g1, g2 = out if out is not None else (torch.empty_like(in1), torch.empty_like(in2))
     with torch.cuda.device_of(in1):
         check(lib().fn2_correlation_backward_ex(_p(in1), _p(in2), _p(gout), _p(g1), _p(g2), _dtype_code(in1), B, C, H,
                                                 W, pad, k, md, s1, s2, algo, _stream(in1)),

@@ -73,6 +73,13 @@ if a.bwd:
         torch.cuda.synchronize()
         ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
         r = {"median_us": round(ts[len(ts) // 2], 2), "min_us": round(ts[0], 2)}
+        if algo >= 100 and (algo - 140) >= 0 and ((algo - 140) & 128):
+            # instrumented instantiation: s_memtime stamps of one phase of each wave of one workgroup (100 MHz ticks)
+            torch.cuda.synchronize()
+            st = g1.view(-1)[:128].view(torch.int64).cpu().view(8, 8)
+            t0 = int(st[:, :7][st[:, :7] > 0].min())
+            for w in range(8):
+                print("   wave", w, [int(v) - t0 if v > 0 else None for v in st[w, :7]])
         if a.check:
             if refb is None:
                 refb = fn2_capi.correlation_backward(in1, in2, gout, a.md, 1, a.md, 1, 2, algo=1)

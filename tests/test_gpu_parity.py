@@ -248,6 +248,86 @@ def test_correlation_mfma_backward_vs_oracle(dev, oracle, case):
         assert e1 <= 5e-6 * scale and e2 <= 5e-6 * scale, (algo, e1, e2)   # fp32 sums in a different order only
 
 
+BWD_BF16_CASES = [  # B, C, H, W, md: the bf16x3 backward kernel's domain (radius 10, C % 64 == 0, W % 4 == 0)
+    (1, 64, 6, 8, 20), (2, 64, 8, 8, 20), (1, 64, 16, 24, 20), (1, 64, 10, 40, 20), (1, 64, 8, 132, 20),
+    (1, 128, 8, 8, 21), (1, 64, 14, 36, 20), (1, 64, 46, 64, 20), (3, 64, 22, 68, 21),
+]
+
+
+@pytest.mark.parametrize("case", BWD_BF16_CASES)
+def test_correlation_bf16x3_backward_vs_oracle(dev, oracle, case):
+    """The exact-split bf16 backward kernel (32-px tiles = shipped, 64-px tiles = algo 105) and the automatic path,
+    against the oracle; every gradient element must be written."""
+    import fn2_capi
+    B, C, H, W, md = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W + md + 2)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    go = rng.standard_normal((B, 441, H, W)).astype(np.float32)
+    ad, bd, gd = to_dev(a, dev), to_dev(b, dev), to_dev(go, dev)
+    r1, r2 = oracle.corr_bwd(a, b, go, md, 1, md, 1, 2)
+    scale = max(1.0, float(np.abs(r1).max()))
+    for algo in (fn2_capi.FN2_CORR_MFMA_BF16X3, 105, fn2_capi.FN2_CORR_AUTO):
+        g1 = torch.full((B, C, H, W), float("nan"), device=dev)
+        g2 = torch.full((B, C, H, W), float("nan"), device=dev)
+        fn2_capi.correlation_backward(ad, bd, gd, md, 1, md, 1, 2, algo=algo, out=(g1, g2))
+        n1, n2 = g1.cpu().numpy(), g2.cpu().numpy()
+        assert np.isfinite(n1).all() and np.isfinite(n2).all(), "unwritten gradient elements"
+        e1, e2 = max_abs(n1, r1), max_abs(n2, r2)
+        assert e1 <= TOL and e2 <= TOL, (algo, e1, e2)
+        assert e1 <= 5e-6 * scale and e2 <= 5e-6 * scale, (algo, e1, e2)
+
+
+def test_correlation_bf16x3_backward_rejects_outside_domain(dev):
+    import fn2_capi
+    x = torch.randn(1, 32, 8, 8, device=dev)          # C % 64 != 0
+    go = torch.randn(1, 441, 8, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        fn2_capi.correlation_backward(x, x, go, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_BF16X3)
+    x = torch.randn(1, 64, 8, 8, device=dev)          # radius 6
+    go = torch.randn(1, 169, 8, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        fn2_capi.correlation_backward(x, x, go, 12, 1, 12, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_BF16X3)
+    g1, g2 = fn2_capi.correlation_backward(x, x, go, 12, 1, 12, 1, 2)   # automatic: falls back to the fp32 MFMA kernel
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+
+
+def test_correlation_backward_accuracy_vs_fp64(dev):
+    """Backward at the BASELINE size: against an fp64 reference (autograd through an fp64 correlation) the bf16x3 kernel
+    is as accurate as the fp32 MFMA kernel; plus linearity in gradOutput and batch independence."""
+    import fn2_capi
+    import torch.nn.functional as F
+    B, C, H, W = 2, 256, 48, 64
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(B, C, H, W, generator=g).to(dev)
+    x2 = torch.randn(B, C, H, W, generator=g).to(dev)
+    go = torch.randn(B, 441, H, W, generator=g).to(dev)
+    a64, b64 = x1.double().requires_grad_(True), x2.double().requires_grad_(True)
+    p2 = F.pad(b64, (20, 20, 20, 20))
+    loss = 0.0
+    for tj in range(21):
+        for ti in range(21):
+            o = (a64 * p2[:, :, 2 * tj:2 * tj + H, 2 * ti:2 * ti + W]).mean(1)
+            loss = loss + (o * go[:, tj * 21 + ti].double()).sum()
+    loss.backward()
+    r1, r2 = a64.grad, b64.grad
+    errs = {}
+    for name, algo in (("f32", fn2_capi.FN2_CORR_MFMA_F32), ("bf16x3", fn2_capi.FN2_CORR_MFMA_BF16X3)):
+        g1, g2 = fn2_capi.correlation_backward(x1, x2, go, 20, 1, 20, 1, 2, algo=algo)
+        errs[name] = max(float((g1.double() - r1).abs().max()), float((g2.double() - r2).abs().max()))
+    tol = 3e-6 * float(r1.abs().max())
+    assert errs["f32"] <= tol and errs["bf16x3"] <= tol, (errs, tol)
+    assert errs["bf16x3"] <= 3.0 * errs["f32"], errs
+    # linearity in gradOutput, batch independence (automatic path)
+    go2 = torch.randn(B, 441, H, W, generator=g).to(dev)
+    s1, s2 = fn2_capi.correlation_backward(x1, x2, go + go2, 20, 1, 20, 1, 2)
+    p1, p2_ = fn2_capi.correlation_backward(x1, x2, go, 20, 1, 20, 1, 2)
+    q1, q2 = fn2_capi.correlation_backward(x1, x2, go2, 20, 1, 20, 1, 2)
+    assert float((s1 - p1 - q1).abs().max()) <= 5e-6 and float((s2 - p2_ - q2).abs().max()) <= 5e-6
+    t1, t2 = fn2_capi.correlation_backward(x1[1:2].contiguous(), x2[1:2].contiguous(), go[1:2].contiguous(), 20, 1, 20, 1, 2)
+    assert torch.equal(t1[0], p1[1]) and torch.equal(t2[0], p2_[1])
+
+
 @pytest.mark.parametrize("dist", ["normal", "leaky"])
 def test_correlation_full_size_vs_oracle(dev, oracle, dist):
     """BASELINE.json configs[1]: fwd+bwd on 8x256x48x64 fp32, <= 1e-4 max-abs (oracle on 2 of the
