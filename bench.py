@@ -225,6 +225,16 @@ def main():
             except Exception:
                 traffic = None
         pairs = CORR["B"] * args.steps * world
+        # empirical streaming ceiling of this box: device-to-device copy of 1 GiB, read + write bytes
+        src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for s_, e_ in cev:
+            s_.record(); dst.copy_(src); e_.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * src.numel() * 4 / (min(s_.elapsed_time(e_) for s_, e_ in cev) * 1e-3) / 1e9
+        del src, dst
         line = {
             "metric": "image-pairs/sec",
             "value": round(pairs / elapsed, 3),
@@ -256,6 +266,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(cf["achieved_GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "copy_ceiling_GBps": round(copy_gbs, 1),
                 "launch_ms": cf["ms"],
                 "algorithmic_bytes": cf["algorithmic_bytes"],
             },

@@ -33,6 +33,36 @@ int correlation_forward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &
     return 1;
 }
 
+// N1, not in the reference module: correlation forward + LeakyReLU(negative_slope) written straight into
+// channels [channel_offset, channel_offset + nOut) of `buffer` (N x Ctot x oH x oW, contiguous) -- the
+// torch.cat((conv_redir, corr), 1) input of conv3_1 (FlowNetC.py:87,92) without the activation and concat passes.
+int correlation_forward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &buffer, int channel_offset,
+                                  double negative_slope, int pad_size, int kernel_size, int max_displacement, int stride1,
+                                  int stride2)
+{
+    const char *op = "correlation_cuda.forward_fused";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    check_same(input1, buffer, op, "buffer");
+    TORCH_CHECK(input1.dim() == 4 && input1.sizes() == input2.sizes(), op, ": inputs must be 4-D and equally shaped");
+    const int dt = dtype_of(input1, op);
+    const int B = input1.size(0), C = input1.size(1), H = input1.size(2), W = input1.size(3);
+    int nOut = 0, oH = 0, oW = 0;
+    check_rc(fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut, &oH,
+                                          &oW), op);
+    TORCH_CHECK(buffer.dim() == 4 && buffer.is_contiguous() && buffer.size(0) == B && buffer.size(2) == oH &&
+                    buffer.size(3) == oW && channel_offset >= 0 && channel_offset + nOut <= buffer.size(1),
+                op, ": buffer ", buffer.sizes(), " cannot hold ", nOut, " channels of ", oH, "x", oW, " at channel ",
+                channel_offset);
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor a = input1.contiguous(), b = input2.contiguous();
+    char *dst = static_cast<char *>(buffer.data_ptr()) + (int64_t)channel_offset * oH * oW * buffer.element_size();
+    check_rc(fn2_correlation_forward_fused(a.data_ptr(), b.data_ptr(), dst, buffer.size(1) * (int64_t)oH * oW,
+                                           (float)negative_slope, dt, B, C, H, W, pad_size, kernel_size,
+                                           max_displacement, stride1, stride2, FN2_CORR_AUTO, current_stream(input1)), op);
+    return 1;
+}
+
 // correlation_backward_cuda (correlation_cuda.cc:89-167)
 int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &rInput1, at::Tensor &rInput2,
                              at::Tensor &gradOutput, at::Tensor &gradInput1, at::Tensor &gradInput2, int pad_size,
@@ -71,4 +101,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.doc() = "FlowNet2 correlation layer, gfx950 HIP kernels (drop-in for the reference correlation_cuda)";
     m.def("forward", &correlation_forward_hip, "Correlation forward (HIP, gfx950)");
     m.def("backward", &correlation_backward_hip, "Correlation backward (HIP, gfx950)");
+    m.def("forward_fused", &correlation_forward_fused_hip,
+          "Correlation forward + LeakyReLU written into a channel slice of a concat buffer (inference)");
 }

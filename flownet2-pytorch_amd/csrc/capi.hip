@@ -40,10 +40,10 @@ extern "C" int fn2_correlation_output_shape(int H, int W, int pad_size, int kern
     return FN2_OK;
 }
 
-extern "C" int fn2_correlation_forward_ex(const void *in1, const void *in2, void *out, int dtype,
-                                          int B, int C, int H, int W,
-                                          int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
-                                          int algo, void *stream)
+extern "C" int fn2_correlation_forward_fused(const void *in1, const void *in2, void *out, int64_t out_batch_stride,
+                                             float negative_slope, int dtype, int B, int C, int H, int W,
+                                             int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                             int algo, void *stream)
 {
     using namespace fn2;
     const size_t es = dtype_size(dtype);
@@ -51,20 +51,37 @@ extern "C" int fn2_correlation_forward_ex(const void *in1, const void *in2, void
     CorrP p;
     int rc = corr_make_params(p, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2);
     if (rc != FN2_OK) return rc;
+    if (out_batch_stride < p.out_bs || !(negative_slope == negative_slope)) return FN2_EINVAL;
+    p.out_bs = out_batch_stride;
+    p.slope = negative_slope;
     if (B == 0) return FN2_OK;
     if (!in1 || !in2 || !out) return FN2_EINVAL;
     if (!aligned(in1, es) || !aligned(in2, es) || !aligned(out, es)) return FN2_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool mfma_ok = corr_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
-                                                  stride2) && aligned(in1, 8) && aligned(in2, 8) && aligned(out, 8);
+                                                  stride2) && aligned(in1, 8) && aligned(in2, 8) && aligned(out, 8) &&
+                         (out_batch_stride % 2 == 0);
     const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || algo >= 100);
     if (wants_mfma && !mfma_ok) return FN2_EUNSUPPORTED;
     if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok))
         return corr_forward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
-                                     static_cast<float *>(out), B, C, H, W, max_displacement,
+                                     static_cast<float *>(out), p.out_bs, p.slope, B, C, H, W, max_displacement,
                                      algo, s); // 0 auto, 2 fp32 MFMA, 3 bf16x3, >= 100 profiling instantiations
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_forward_direct(in1, in2, out, dtype, p, s);
+}
+
+extern "C" int fn2_correlation_forward_ex(const void *in1, const void *in2, void *out, int dtype,
+                                          int B, int C, int H, int W,
+                                          int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                          int algo, void *stream)
+{
+    int nOut = 0, oH = 0, oW = 0;
+    const int rc = fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut,
+                                                &oH, &oW);
+    if (rc != FN2_OK) return rc;
+    return fn2_correlation_forward_fused(in1, in2, out, (int64_t)nOut * oH * oW, 1.0f, dtype, B, C, H, W, pad_size,
+                                         kernel_size, max_displacement, stride1, stride2, algo, stream);
 }
 
 extern "C" int fn2_correlation_forward(const void *in1, const void *in2, void *out, int dtype,

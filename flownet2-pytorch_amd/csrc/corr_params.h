@@ -8,6 +8,8 @@ struct CorrP {
     int B, C, H, W;            // input1 / input2 shape (NCHW)
     int pad, k, md, s1, s2;    // pad_size, kernel_size, max_displacement, stride1, stride2
     int kr, dr, D, nOut, oH, oW;
+    long out_bs;               // elements between batch items of the output (nOut*oH*oW unless it is a slice of a larger buffer)
+    float slope;               // LeakyReLU negative slope applied to the output (1 = none)
 };
 
 int corr_make_params(CorrP &p, int B, int C, int H, int W, int pad, int k, int md, int s1, int s2);
@@ -15,8 +17,8 @@ int corr_forward_direct(const void *in1, const void *in2, void *out, int dtype, 
 int corr_backward_direct(const void *in1, const void *in2, const void *gout, void *g1, void *g2, int dtype,
                          const CorrP &p, hipStream_t s);
 bool corr_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
-int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
-                          int tune, hipStream_t s);
+int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, long out_bs, float slope, int B, int C, int H,
+                          int W, int md, int tune, hipStream_t s);
 
 bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void corr_fwd_direct(const T *__restrict__ in1
             }
         }
         const int nelems = p.k * p.k * p.C;
-        out[idx] = (T)(acc / nelems); // (:143)
+        float res = acc / nelems; // (:143)
+        if (p.slope != 1.0f) res = res > 0.0f ? res : (float)(T)res * p.slope;   // fused LeakyReLU (FlowNetC.py:87) on the stored value
+        out[(long)n * p.out_bs + (idx - (long)n * p.nOut * p.oH * p.oW)] = (T)res;
     }
 }
 
@@ -151,6 +153,8 @@ int corr_make_params(CorrP &p, int B, int C, int H, int W, int pad, int k, int m
     p.dr = md / s2;
     p.D = 2 * p.dr + 1;
     int rc = fn2_correlation_output_shape(H, W, pad, k, md, s1, s2, &p.nOut, &p.oH, &p.oW);
+    p.out_bs = (long)p.nOut * p.oH * p.oW;
+    p.slope = 1.0f;
     return rc;
 }
 

@@ -57,6 +57,8 @@ typedef float __attribute__((ext_vector_type(2))) f2;
 struct Args {
     const float *in1, *in2;
     float *out;
+    long out_bs;     // elements between batch items of `out` (D*D*H*W unless out is a channel slice of a larger buffer)
+    float slope;     // LeakyReLU negative slope fused into the epilogue (1 = none)
     int C, H, W;     // H, W even
     int dr, D, NV;   // displacement radius (lattice), 2dr+1, B blocks per A block per axis
     int NRG, NXT;    // row groups per parity, x tiles
@@ -127,7 +129,7 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
                 const int IL = 4 * rg + ai;
                 if (tj < 0 || tj >= p.D || IL >= HL) continue; // wave-uniform
                 const int y = 2 * IL + py;
-                float *orow = p.out + (((long)n * p.D * p.D + (long)tj * p.D) * p.H + y) * p.W + xg;
+                float *orow = p.out + (long)n * p.out_bs + ((long)tj * p.D * p.H + y) * p.W + xg;
                 const float *srow = Os + (long)pl * p.D * O_RS + 2 * hx;
                 for (int ti0 = 0; ti0 < p.D; ti0 += 2) {
                     const int ti = ti0 + hr;
@@ -135,6 +137,10 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
                         f2 val = *reinterpret_cast<const f2 *>(srow + ti * O_RS);
                         if (pow2) { val[0] *= rC; val[1] *= rC; }
                         else { val[0] /= fC; val[1] /= fC; }
+                        if (p.slope != 1.0f) {   // fused LeakyReLU (FlowNetC.py:87), wave-uniform branch
+                            val[0] = val[0] > 0.0f ? val[0] : val[0] * p.slope;
+                            val[1] = val[1] > 0.0f ? val[1] : val[1] * p.slope;
+                        }
                         *reinterpret_cast<f2 *>(orow + (long)ti * HW) = val;
                     }
                 }
@@ -788,12 +794,14 @@ static int launch_nv(const Args &a, long ntasks, hipStream_t s)
 
 // tune: 0 = fastest applicable kernel (bf16x3 split where it applies, else fp32 MFMA); 2 = fp32 MFMA only
 //       (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain); 3 = bf16x3 only; >= 100 profiling instantiations
-int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, int B, int C, int H, int W, int md,
-                          int tune, hipStream_t s)
+int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, long out_bs, float slope, int B, int C, int H,
+                          int W, int md, int tune, hipStream_t s)
 {
     if (!aligned(in1, 8) || !aligned(in2, 8)) return FN2_EALIGN;
+    if (out_bs % 2 != 0) return FN2_EALIGN;   // output rows are stored as float2
     mf::Args a;
     a.in1 = in1; a.in2 = in2; a.out = out;
+    a.out_bs = out_bs; a.slope = slope;
     a.C = C; a.H = H; a.W = W;
     a.dr = md / 2; a.D = 2 * a.dr + 1; a.NV = 1 + (a.dr + 1) / 2;
     const int HL = H / 2;

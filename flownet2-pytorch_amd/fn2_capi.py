@@ -14,7 +14,7 @@ FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32, FN2_CORR_MFMA_BF16X3 = 0, 1, 
 
 EXPORTS = [
     "fn2_strerror", "fn2_abi_version", "fn2_correlation_output_shape",
-    "fn2_correlation_forward", "fn2_correlation_forward_ex",
+    "fn2_correlation_forward", "fn2_correlation_forward_ex", "fn2_correlation_forward_fused",
     "fn2_correlation_backward", "fn2_correlation_backward_ex",
     "fn2_resample2d_forward", "fn2_resample2d_backward",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
@@ -76,6 +76,21 @@ def correlation_forward(in1, in2, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=No
         check(lib().fn2_correlation_forward_ex(_p(in1), _p(in2), _p(out), _dtype_code(in1), B, C, H, W, pad, k, md, s1,
                                                s2, algo, _stream(in1)), "fn2_correlation_forward_ex")
     return out
+
+
+def correlation_forward_fused(in1, in2, buffer, channel_offset, negative_slope, pad, k, md, s1, s2, algo=FN2_CORR_AUTO):
+    """LeakyReLU(correlation) written into channels [channel_offset, +nOut) of the contiguous N x Ctot x oH x oW `buffer`."""
+    import torch
+    B, C, H, W = in1.shape
+    nOut, oH, oW = correlation_output_shape(H, W, pad, k, md, s1, s2)
+    assert buffer.is_contiguous() and buffer.shape[0] == B and tuple(buffer.shape[2:]) == (oH, oW)
+    assert 0 <= channel_offset and channel_offset + nOut <= buffer.shape[1]
+    dst = ctypes.c_void_p(buffer.data_ptr() + channel_offset * oH * oW * buffer.element_size())
+    with torch.cuda.device_of(in1):
+        check(lib().fn2_correlation_forward_fused(_p(in1), _p(in2), dst, ctypes.c_int64(buffer.shape[1] * oH * oW),
+                                                  ctypes.c_float(negative_slope), _dtype_code(in1), B, C, H, W, pad, k,
+                                                  md, s1, s2, algo, _stream(in1)), "fn2_correlation_forward_fused")
+    return buffer
 
 
 def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=None):

@@ -58,3 +58,28 @@ class Correlation(nn.Module):
     def extra_repr(self):
         return (f"pad_size={self.pad_size}, kernel_size={self.kernel_size}, max_displacement={self.max_displacement}, "
                 f"stride1={self.stride1}, stride2={self.stride2}")
+
+
+class CorrelationLeakyReLUCat(nn.Module):
+    """SURVEY.md 8f N1 (inference): ``torch.cat((redir, leaky_relu(corr(input1, input2), slope)), 1)`` with the
+    activation and the concat fused into the correlation epilogue -- the three statements FlowNetC.py:86-87,92 as one
+    kernel pass over the 441-channel cost volume instead of three.  No autograd (use ``Correlation`` for training).
+
+        cat = CorrelationLeakyReLUCat(20, 1, 20, 1, 2, negative_slope=0.1)(out_conv3a, out_conv3b, out_conv_redir)
+    """
+
+    def __init__(self, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, negative_slope=0.1):
+        super().__init__()
+        self.corr_params = (pad_size, kernel_size, max_displacement, stride1, stride2)
+        self.negative_slope = negative_slope
+
+    @torch.no_grad()
+    def forward(self, input1, input2, redir):
+        pad, k, md, s1, s2 = self.corr_params
+        n_out = ((md // s2) * 2 + 1) ** 2
+        B, Cr, oH, oW = redir.shape
+        buf = redir.new_empty((B, Cr + n_out, oH, oW))
+        buf[:, :Cr].copy_(redir)
+        with torch.cuda.device_of(input1):
+            correlation_cuda.forward_fused(input1, input2, buf, Cr, float(self.negative_slope), pad, k, md, s1, s2)
+        return buf

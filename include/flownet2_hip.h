@@ -84,6 +84,16 @@ int fn2_correlation_forward_ex(const void *in1, const void *in2, void *out, int 
                                int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
                                int algo, void *stream);
 
+/* "Next" row N1: the same forward with the two passes that follow it in FlowNetC fused into the epilogue:
+ * LeakyReLU(negative_slope) on the cost volume (FlowNetC.py:87; 1.0f = no activation) and the store into a channel slice
+ * of a larger NCHW buffer, i.e. the torch.cat((conv_redir, corr), 1) input of conv3_1 (FlowNetC.py:92): `out` points at the
+ * first correlation channel of batch item 0 and out_batch_stride (elements, >= nOut*oH*oW) is that buffer's batch stride.
+ * fn2_correlation_forward_ex == this with out_batch_stride = nOut*oH*oW, negative_slope = 1. */
+int fn2_correlation_forward_fused(const void *in1, const void *in2, void *out, int64_t out_batch_stride,
+                                  float negative_slope, int dtype, int B, int C, int H, int W,
+                                  int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                  int algo, void *stream);
+
 /* Replaces correlation_backward_cuda_kernel (correlation_cuda_kernel.cuh:44-91; kernels
  * correlation_cuda_kernel.cu:150-241 backward_input1, :243-334 backward_input2, host loops
  * :522-554).  grad_out : B x nOut x oH x oW contiguous; grad_in1, grad_in2 : B x C x H x W,

@@ -55,6 +55,9 @@ def test_rejected_calls_return_codes_without_gpu():
     assert lib.fn2_correlation_forward(p, p, p, 0, 1, 4, 4, 4, 0, 1, 20, 1, 2, null) == -1  # empty output
     assert lib.fn2_correlation_backward(p, p, p, p, p, 0, 1, 4, 8, 8, 4, 1, 4, 2, 2, null) == -4  # stride1 != 1
     assert lib.fn2_correlation_forward_ex(p, p, p, 0, 1, 4, 8, 8, 4, 3, 4, 1, 2, 2, null) == -4   # MFMA path needs k=1
+    i64, f32 = ctypes.c_int64, ctypes.c_float
+    assert lib.fn2_correlation_forward_fused(p, p, p, i64(10), f32(0.1), 0, 1, 4, 8, 8, 4, 1, 4, 1, 2, 0, null) == -1  # stride < 25*8*8
+    assert lib.fn2_correlation_forward_fused(p, p, p, i64(3200), f32(0.1), 0, 0, 4, 8, 8, 4, 1, 4, 1, 2, 0, null) == 0   # empty batch
     mis = ctypes.c_void_p(ctypes.addressof(buf) + 2)
     assert lib.fn2_channelnorm_forward(mis, p, 0, 1, 1, 2, 2, null) == -3          # FN2_EALIGN
     assert b"dtype" in lib.fn2_strerror(-2) and lib.fn2_strerror(0) == b"ok"

@@ -223,6 +223,53 @@ def test_correlation_mfma_vs_oracle(dev, oracle, case):
         assert np.isfinite(b3.cpu().numpy()).all() and max_abs(b3.cpu().numpy(), ref) <= 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, torch.float32), (1, 32, 10, 40, 12, torch.float32),
+                                  (8, 256, 48, 64, 20, torch.float32), (1, 16, 8, 130, 20, torch.float32),
+                                  (1, 8, 9, 7, 4, torch.float16), (2, 4, 6, 6, 2, torch.float64)])
+def test_correlation_fused_leakyrelu_cat(dev, oracle, case):
+    """LeakyReLU(0.1)(correlation) written into the channel slice of the conv_redir concat buffer
+    (FlowNetC.py:86-92) -- C ABI entry, pybind function and Module; the other channels of the buffer stay untouched."""
+    import fn2_capi
+    import correlation_cuda
+    from networks.correlation_package.correlation import CorrelationLeakyReLUCat
+    B, C, H, W, md, dtype = case
+    npd = {torch.float32: np.float32, torch.float16: np.float16, torch.float64: np.float64}[dtype]
+    rng = np.random.default_rng(C + H + W + md)
+    a = rng.standard_normal((B, C, H, W)).astype(npd)
+    b = rng.standard_normal((B, C, H, W)).astype(npd)
+    if B == 8:   # full size: the oracle on two batch items only
+        items = (0, 7)
+    else:
+        items = tuple(range(B))
+    D2 = (2 * (md // 2) + 1) ** 2
+    Cr = 32
+    redir = rng.standard_normal((B, Cr, H, W)).astype(npd)
+    ad, bd, rd = to_dev(a, dev), to_dev(b, dev), to_dev(redir, dev)
+    sentinel = 7.0
+    buf = torch.full((B, Cr + D2 + 3, H, W), sentinel, device=dev, dtype=dtype)
+    fn2_capi.correlation_forward_fused(ad, bd, buf, Cr, 0.1, md, 1, md, 1, 2)
+    got = buf.cpu().numpy()
+    assert (got[:, :Cr] == sentinel).all() and (got[:, Cr + D2:] == sentinel).all(), "wrote outside its channel slice"
+    tol = TOL if dtype != torch.float16 else 2e-3
+    for n in items:
+        ref = oracle.corr_fwd(a[n:n + 1].astype(np.float32 if dtype != torch.float64 else np.float64),
+                              b[n:n + 1].astype(np.float32 if dtype != torch.float64 else np.float64), md, 1, md, 1, 2)
+        ref = np.where(ref > 0, ref, ref * npd(0.1).astype(ref.dtype))
+        assert max_abs(got[n:n + 1, Cr:Cr + D2].astype(np.float64), ref.astype(np.float64)) <= tol
+    # pybind entry and Module: cat((redir, leaky(corr)), 1)
+    buf2 = torch.empty((B, Cr + D2, H, W), device=dev, dtype=dtype)
+    buf2[:, :Cr] = rd
+    correlation_cuda.forward_fused(ad, bd, buf2, Cr, 0.1, md, 1, md, 1, 2)
+    assert torch.equal(buf2[:, Cr:], buf[:, Cr:Cr + D2])
+    mod = CorrelationLeakyReLUCat(md, 1, md, 1, 2, negative_slope=0.1)
+    cat = mod(ad, bd, rd)
+    assert torch.equal(cat, buf2)
+    # against the unfused sequence of the reference model on the same kernels
+    from networks.correlation_package.correlation import Correlation
+    unfused = torch.cat((rd, torch.nn.functional.leaky_relu(Correlation(md, 1, md, 1, 2, 1)(ad, bd), 0.1)), 1)
+    assert torch.equal(cat, unfused) or float((cat - unfused).abs().max()) <= (1e-7 if dtype != torch.float16 else 1e-3)
+
+
 BWD_CASES = [  # B, C, H, W, md  (k=1, s1=1, s2=2, pad=md); C % 32 == 0
     (1, 32, 6, 8, 20), (2, 64, 8, 8, 20), (1, 64, 16, 24, 20), (1, 32, 10, 40, 20), (1, 32, 8, 130, 20),
     (1, 32, 12, 16, 4), (2, 64, 10, 12, 6), (1, 32, 6, 6, 2), (1, 96, 14, 18, 10), (1, 32, 20, 72, 14), (1, 128, 8, 8, 21),
