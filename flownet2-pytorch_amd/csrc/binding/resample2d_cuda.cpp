@@ -69,9 +69,36 @@ int resample2d_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &
     return 1;
 }
 
+// N2, not in the reference module: cat(pair, warp(pair[:, C:], flow), flow / div_flow,
+// channelnorm(pair[:, :C] - warped)) in one pass (models.py:133-138).
+int warp_diff_norm_cat_hip(at::Tensor &pair, at::Tensor &flow, at::Tensor &output, double div_flow, bool bilinear)
+{
+    const char *op = "resample2d_cuda.warp_diff_norm_cat";
+    check_gpu(pair, op, "pair");
+    check_same(pair, flow, op, "flow");
+    check_same(pair, output, op, "output");
+    TORCH_CHECK(pair.scalar_type() == at::kFloat, op, ": float32 tensors expected, got ", pair.scalar_type());
+    TORCH_CHECK(pair.dim() == 4 && flow.dim() == 4 && output.dim() == 4, op, ": tensors must be 4-D");
+    TORCH_CHECK(pair.size(1) % 2 == 0 && pair.size(1) > 0, op, ": pair must hold two images (even channel count), got ",
+                pair.sizes());
+    const int B = pair.size(0), C = pair.size(1) / 2, H = pair.size(2), W = pair.size(3);
+    TORCH_CHECK(flow.size(0) == B && flow.size(1) == 2 && flow.size(2) == H && flow.size(3) == W, op, ": flow ",
+                flow.sizes(), " does not match pair ", pair.sizes());
+    TORCH_CHECK(output.size(0) == B && output.size(1) == 3 * C + 3 && output.size(2) == H && output.size(3) == W &&
+                    output.is_contiguous(),
+                op, ": output must be contiguous [", B, ", ", 3 * C + 3, ", ", H, ", ", W, "], got ", output.sizes());
+    c10::DeviceGuard guard(pair.device());
+    at::Tensor p = pair.contiguous(), f = flow.contiguous();
+    check_rc(fn2_warp_diff_norm_cat(p.data_ptr<float>(), f.data_ptr<float>(), output.data_ptr<float>(), (float)div_flow,
+                                    B, C, H, W, bilinear ? 1 : 0, current_stream(pair)), op);
+    return 1;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "FlowNet2 Resample2d layer, gfx950 HIP kernels (drop-in for the reference resample2d_cuda)";
     m.def("forward", &resample2d_forward_hip, "Resample2D forward (HIP, gfx950)");
     m.def("backward", &resample2d_backward_hip, "Resample2D backward (HIP, gfx950)");
+    m.def("warp_diff_norm_cat", &warp_diff_norm_cat_hip,
+          "cat(pair, warp(second image, flow), flow / div_flow, ||first image - warped||) in one pass (inference)");
 }

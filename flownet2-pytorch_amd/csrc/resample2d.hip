@@ -215,11 +215,16 @@ __device__ __forceinline__ void lds_add_f32(float *addr, float v)
     } while (old != assumed);
 }
 
-template <int TH, int TW, int R>
+// FUSE (models.py:133-138): `img` is the second image of a B x 2C x H x W pair tensor `pair`, and the
+// kernel writes cat((pair, warped, flow / div_flow, ||pair[:, :C] - warped||_2), 1) = B x (3C+3) x H x W in one pass:
+// the warped channel, the copy of both images (the second one comes from the LDS window), the squared difference
+// accumulated in channel order as channelnorm_kernel.cu:41-52 does, then the flow and the norm planes.
+template <int TH, int TW, int R, bool FUSE = false>
 __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__restrict__ img, ImgStrides is,
                                                             const float *__restrict__ flow, float *__restrict__ out,
                                                             int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
-                                                            int bilinear)
+                                                            int bilinear, const float *__restrict__ pair = nullptr,
+                                                            float div_flow = 1.0f)
 {
     // 1024 threads, <= 64 VGPRs: two workgroups (32 waves) per CU.  Per-pixel state is 4 registers: the four corners are
     // base + {0, dx, dy*stride, both} (clamping can only merge neighbours) and the double-precision weights are rebuilt per
@@ -238,11 +243,13 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
     const long HW = (long)H * W;
 
     float alpha[PPT], beta[PPT];
+    float ssq[FUSE ? PPT : 1];
     int base[PPT], flags[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        if (FUSE) ssq[k] = 0.0f;
         alpha[k] = beta[k] = 0.0f;
         base[k] = flags[k] = 0;
         if (!((x < W) && (y < H))) continue;
@@ -323,10 +330,36 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
             } else {
                 val = i00;
             }
-            out[((long)b * C + c) * HW + (y * W + x)] = val;
+            if (!FUSE) out[((long)b * C + c) * HW + (y * W + x)] = val;
+            else {
+                const int pix = y * W + x;
+                float *ob = out + (long)b * (3 * C + 3) * HW + pix;
+                const float v0 = pair[((long)b * 2 * C + c) * HW + pix];
+                const float v1 = wc[(y - wy0) * WW + (x - wx0)];        // the pixel itself is always inside the window
+                ob[(long)c * HW] = v0;
+                ob[(long)(C + c) * HW] = v1;
+                ob[(long)(2 * C + c) * HW] = val;
+                const float d = v0 - val;                               // models.py:134
+                ssq[k] = ssq[k] + d * d;                                // channelnorm_kernel.cu:47-50
+            }
         }
         if (c + 1 < C) win_write(win[(c + 1) & 1]);
         __syncthreads();
+    }
+    if (FUSE) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            if (!(flags[k] & LIVE)) continue;
+            const int pix = y * W + x;
+            float *ob = out + (long)b * (3 * C + 3) * HW + pix;
+            // models.py:138 `flow / self.div_flow` on a GPU tensor: PyTorch multiplies by the fp32 reciprocal of a scalar divisor
+            const float inv_div = 1.0f / div_flow;
+            ob[(long)(3 * C) * HW] = flow[(long)b * 2 * HW + pix] * inv_div;
+            ob[(long)(3 * C + 1) * HW] = flow[(long)b * 2 * HW + HW + pix] * inv_div;
+            ob[(long)(3 * C + 2) * HW] = __fsqrt_rn(ssq[k]);                                // channelnorm_kernel.cu:52
+        }
     }
 }
 
@@ -505,6 +538,56 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     }
 }
 
+// N2 for shapes the tiled kernel does not take: one lane per pixel, corners gathered from global memory.
+__global__ __launch_bounds__(256) void warp_diff_norm_cat_kernel(const float *__restrict__ pair, const float *__restrict__ flow,
+                                                                 float *__restrict__ out, int C, int H, int W, long npix,
+                                                                 int bilinear, float div_flow)
+{
+    const long HW = (long)H * W;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(g % W);
+        const long row = g / W;
+        const int y = (int)(row % H), b = (int)(row / H);
+        const long pix = (long)y * W + x;
+        const float dx = flow[(long)b * 2 * HW + pix], dy = flow[(long)b * 2 * HW + HW + pix];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        int xL, xR, yT, yB;
+        double a = 0., be = 0.;
+        if (bilinear) {
+            const float fx = floorf(xf), fy = floorf(yf);
+            a = (double)(xf - fx); be = (double)(yf - fy);
+            xL = clampi(f2i_sat(fx), 0, W - 1); xR = clampi(f2i_sat(fx + 1.0f), 0, W - 1);
+            yT = clampi(f2i_sat(fy), 0, H - 1); yB = clampi(f2i_sat(fy + 1.0f), 0, H - 1);
+        } else {
+            xL = xR = clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1);
+            yT = yB = clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1);
+        }
+        float *ob = out + (long)b * (3 * C + 3) * HW + pix;
+        float ssq = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float *I = pair + ((long)b * 2 * C + C + c) * HW;
+            float val;
+            if (bilinear) {
+                val = 0.0f;
+                val = val + (float)(((1. - a) * (1. - be)) * (double)I[(long)yT * W + xL]);
+                val = val + (float)((a * (1. - be)) * (double)I[(long)yT * W + xR]);
+                val = val + (float)(((1. - a) * be) * (double)I[(long)yB * W + xL]);
+                val = val + (float)((a * be) * (double)I[(long)yB * W + xR]);
+            } else val = I[(long)yT * W + xL];
+            const float v0 = pair[((long)b * 2 * C + c) * HW + pix];
+            ob[(long)c * HW] = v0;
+            ob[(long)(C + c) * HW] = I[pix];
+            ob[(long)(2 * C + c) * HW] = val;
+            const float d = v0 - val;
+            ssq = ssq + d * d;
+        }
+        const float inv_div = 1.0f / div_flow;   // as PyTorch divides a GPU tensor by a scalar
+        ob[(long)(3 * C) * HW] = dx * inv_div;
+        ob[(long)(3 * C + 1) * HW] = dy * inv_div;
+        ob[(long)(3 * C + 2) * HW] = __fsqrt_rn(ssq);
+    }
+}
+
 // Tile height of the tiled kernels (two 1024-thread workgroups per CU = 512 resident tiles): the height that needs fewer
 // window rows over all rounds; 48 turns FlowNet2's 8 x 384 x 512 into exactly one round.
 static inline int tile_height(int B, int H, int tiles_x)
@@ -611,6 +694,39 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
     } else {
         hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out,
                            grad_img, grad_flow, C, Hi, Wi, H, W, npix);
+    }
+    return launch_status();
+}
+
+extern "C" int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, float div_flow,
+                                      int B, int C, int H, int W, int bilinear, void *stream)
+{
+    using namespace fn2;
+    if (B < 0 || C < 1 || H < 1 || W < 1 || !(div_flow == div_flow) || div_flow == 0.0f) return FN2_EINVAL;
+    if ((long)B * H * W == 0) return FN2_OK;
+    if (!pair || !flow || !out) return FN2_EINVAL;
+    if (!aligned(pair, 4) || !aligned(flow, 4) || !aligned(out, 4)) return FN2_EALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    const bool tiled_ok = (W % 4 == 0) && aligned(pair, 16) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
+    if (tiled_ok) {
+        ImgStrides is;
+        is.b = 2 * C * HW; is.c = HW; is.h = W; is.w = 1;
+        const float *img1 = pair + (long)C * HW;
+        constexpr int TW = 64;
+        const int tiles_x = (W + TW - 1) / TW;
+#define FN2_WF(TH)                                                                                                      \
+    do {                                                                                                                \
+        const int tiles_y = (H + TH - 1) / TH;                                                                          \
+        hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16, true>), dim3((unsigned)((long)B * tiles_x * tiles_y)),       \
+                           dim3(1024), 0, s, img1, is, flow, out, C, H, W, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0, \
+                           pair, div_flow);                                                                             \
+    } while (0)
+        if (tile_height(B, H, tiles_x) == 48) FN2_WF(48); else FN2_WF(32);
+#undef FN2_WF
+    } else {
+        hipLaunchKernelGGL(warp_diff_norm_cat_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, out, C, H, W,
+                           npix, (bilinear & 1) ? 1 : 0, div_flow);
     }
     return launch_status();
 }

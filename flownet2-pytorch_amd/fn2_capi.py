@@ -16,7 +16,7 @@ EXPORTS = [
     "fn2_strerror", "fn2_abi_version", "fn2_correlation_output_shape",
     "fn2_correlation_forward", "fn2_correlation_forward_ex", "fn2_correlation_forward_fused",
     "fn2_correlation_backward", "fn2_correlation_backward_ex",
-    "fn2_resample2d_forward", "fn2_resample2d_backward",
+    "fn2_resample2d_forward", "fn2_resample2d_backward", "fn2_warp_diff_norm_cat",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
 ]
 
@@ -102,3 +102,16 @@ def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO,
                                                 W, pad, k, md, s1, s2, algo, _stream(in1)),
               "fn2_correlation_backward_ex")
     return g1, g2
+
+
+def warp_diff_norm_cat(pair, flow, div_flow=20.0, bilinear=True):
+    """cat(pair, warp(pair[:, C:], flow), flow / div_flow, ||pair[:, :C] - warped||_2) (models.py:133-138) in one pass."""
+    import torch
+    B, C2, H, W = pair.shape
+    C = C2 // 2
+    assert pair.is_contiguous() and flow.is_contiguous() and pair.dtype == torch.float32 and C2 == 2 * C
+    out = torch.empty((B, 3 * C + 3, H, W), dtype=pair.dtype, device=pair.device)
+    with torch.cuda.device_of(pair):
+        check(lib().fn2_warp_diff_norm_cat(_p(pair), _p(flow), _p(out), ctypes.c_float(div_flow), B, C, H, W,
+                                           1 if bilinear else 0, _stream(pair)), "fn2_warp_diff_norm_cat")
+    return out

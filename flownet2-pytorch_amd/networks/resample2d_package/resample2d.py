@@ -47,3 +47,25 @@ class Resample2d(nn.Module):
 
     def forward(self, input1, input2):
         return Resample2dFunction.apply(input1, input2, self.kernel_size, self.bilinear)
+
+
+class WarpDiffNormCat(nn.Module):
+    """SURVEY.md 8f N2 (inference): the five statements models.py:133-138 --
+
+        resampled = Resample2d()(x[:, 3:], flow);  diff = x[:, :3] - resampled;  norm = ChannelNorm()(diff)
+        concat = torch.cat((x, resampled, flow / div_flow, norm), dim=1)
+
+    -- as one kernel pass (the reference makes x[:, 3:] contiguous, writes and re-reads the warped image, the difference
+    and the norm, then copies all twelve channels again for the concat).  No autograd."""
+
+    def __init__(self, div_flow=20.0, bilinear=True):
+        super().__init__()
+        self.div_flow = div_flow
+        self.bilinear = bilinear
+
+    @torch.no_grad()
+    def forward(self, x, flow):
+        b, c2, h, w = x.shape
+        out = x.new_empty((b, c2 + c2 // 2 + 3, h, w))
+        resample2d_cuda.warp_diff_norm_cat(x, flow, out, float(self.div_flow), self.bilinear)
+        return out

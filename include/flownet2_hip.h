@@ -134,6 +134,18 @@ int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const 
                             int B, int C, int Hi, int Wi, int H, int W,
                             int kernel_size, int bilinear, void *stream);
 
+/* "Next" row N2: the warp -> difference -> channel norm -> concat sequence of FlowNet2
+ * (models.py:133-138, repeated at :145-150, :157-161, :170-174) as ONE pass:
+ *   pair : B x 2C x H x W contiguous (channels [0,C) = first image, [C,2C) = second image)
+ *   flow : B x 2 x H x W contiguous
+ *   out  : B x (3C+3) x H x W contiguous, fully written
+ *        = cat(pair, Resample2d(pair[:, C:], flow), flow / div_flow, ChannelNorm(pair[:, :C] - warped)), dim 1
+ * with the arithmetic of the unfused reference kernels (resample2d_kernel.cu:15-72, channelnorm_kernel.cu:18-60);
+ * flow / div_flow is flow * (1.0f / div_flow), which is what PyTorch computes for a GPU tensor divided by a scalar.
+ * float32; kernel_size 1. */
+int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, float div_flow,
+                           int B, int C, int H, int W, int bilinear, void *stream);
+
 /* Replaces channelnorm_kernel_forward (channelnorm_kernel.cuh:5-8; kernel
  * channelnorm_kernel.cu:18-60).  in : B x C x H x W contiguous, out : B x 1 x H x W contiguous.
  * norm_deg is accepted and ignored by the reference kernels (always L2); not part of this ABI. */

@@ -1,0 +1,54 @@
+"""Timing of the fused "next" rows against the unfused statement sequences of the reference models
+on the same HIP layers.  Prints one JSON object; run on the GPU box."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
+import torch
+import torch.nn.functional as F
+from networks.correlation_package.correlation import Correlation, CorrelationLeakyReLUCat
+from networks.resample2d_package.resample2d import Resample2d, WarpDiffNormCat
+from networks.channelnorm_package.channelnorm import ChannelNorm
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    ev = []
+    for _ in range(n):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); ev.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
+    return round(ts[len(ts) // 2], 1)
+
+
+res = {}
+with torch.no_grad():
+    # N1: FlowNetC.py:86-92 at bs 8 @ 384x512 -> conv3 maps 8 x 256 x 48 x 64, conv_redir 8 x 32 x 48 x 64
+    a = torch.randn(8, 256, 48, 64, generator=g).to(dev)
+    b = torch.randn(8, 256, 48, 64, generator=g).to(dev)
+    redir = torch.randn(8, 32, 48, 64, generator=g).to(dev)
+    corr, fused = Correlation(20, 1, 20, 1, 2, 1), CorrelationLeakyReLUCat(20, 1, 20, 1, 2, 0.1)
+    res["N1_unfused_us"] = timeit(lambda: torch.cat((redir, F.leaky_relu(corr(a, b), 0.1, inplace=True)), 1))
+    res["N1_fused_us"] = timeit(lambda: fused(a, b, redir))
+    assert torch.equal(fused(a, b, redir), torch.cat((redir, F.leaky_relu(corr(a, b), 0.1)), 1))
+    # N2: models.py:133-138 at bs 8 @ 384x512
+    x = torch.rand(8, 6, 384, 512, generator=g).to(dev)
+    flow = (torch.randn(8, 2, 384, 512, generator=g) * 4.0).to(dev)
+    rs, cn, wd = Resample2d(), ChannelNorm(), WarpDiffNormCat(20.0)
+
+    def unfused():
+        r = rs(x[:, 3:, :, :], flow)
+        d = x[:, :3, :, :] - r
+        return torch.cat((x, r, flow / 20.0, cn(d)), dim=1)
+
+    res["N2_unfused_us"] = timeit(unfused)
+    res["N2_fused_us"] = timeit(lambda: wd(x, flow))
+    assert torch.equal(wd(x, flow), unfused())
+    res["N2_algorithmic_bytes"] = (6 + 2 + 12) * 8 * 384 * 512 * 4
+    res["N2_fused_GBps"] = round(res["N2_algorithmic_bytes"] / (res["N2_fused_us"] * 1e-6) / 1e9, 1)
+print(json.dumps(res))

@@ -152,6 +152,39 @@ def test_resample2d_strided_image_and_accumulate(dev, oracle):
     assert max_abs(gflow.cpu().numpy(), rflow) <= 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 40, 64), (1, 3, 384, 512), (2, 2, 17, 33), (1, 1, 16, 36), (3, 3, 50, 132)])
+@pytest.mark.parametrize("bilinear", [True, False])
+def test_warp_diff_norm_cat(dev, oracle, shape, bilinear):
+    """the fused warp -> difference -> channel norm -> concat pass (models.py:133-138) against the
+    composition of the oracle's resample and channelnorm restatements, and bitwise against the unfused HIP layers."""
+    import fn2_capi
+    import resample2d_cuda  # noqa: F401
+    from networks.resample2d_package.resample2d import Resample2d, WarpDiffNormCat
+    from networks.channelnorm_package.channelnorm import ChannelNorm
+    B, C, H, W = shape
+    rng = np.random.default_rng(B + C + H + W)
+    x = rng.standard_normal((B, 2 * C, H, W)).astype(np.float32)
+    flow = (rng.standard_normal((B, 2, H, W)) * 4.0).astype(np.float32)
+    flow.reshape(-1)[rng.integers(0, flow.size, flow.size // 100)] *= 20.0   # border clamps, far-out samples
+    xd, fd = to_dev(x, dev), to_dev(flow, dev)
+    got = fn2_capi.warp_diff_norm_cat(xd, fd, 20.0, bilinear)
+    assert got.shape == (B, 3 * C + 3, H, W)
+    g = got.cpu().numpy()
+    warped = oracle.resample_fwd(np.ascontiguousarray(x[:, C:]), flow, 1, bilinear)
+    diff = x[:, :C] - warped
+    norm = oracle.chnorm_fwd(diff)
+    scaled = flow * (np.float32(1.0) / np.float32(20.0))   # a GPU tensor / scalar in PyTorch = times the fp32 reciprocal
+    ref = np.concatenate((x, warped, scaled, norm), axis=1)
+    assert np.array_equal(g[:, :2 * C], x)
+    assert np.array_equal(g[:, 3 * C:3 * C + 2], scaled)
+    assert max_abs(g, ref) <= TOL
+    # bit-identical to the unfused HIP layers in the reference model's statement order
+    res = Resample2d(1, bilinear)(xd[:, C:].contiguous(), fd)
+    unf = torch.cat((xd, res, fd / 20.0, ChannelNorm()(xd[:, :C] - res)), dim=1)
+    assert torch.equal(got, unf)
+    assert torch.equal(WarpDiffNormCat(20.0, bilinear)(xd, fd), got)
+
+
 def test_resample2d_rejects_non_float(dev):
     import resample2d_cuda
     a = torch.zeros(1, 3, 8, 8, device=dev, dtype=torch.float64)
