@@ -18,7 +18,8 @@ collective: weak scaling); value = image pairs processed by all ranks / max-over
 Rank 0 prints ONE JSON line.  `roofline` is for the correlation forward kernel (the kernel
 BASELINE.json's metric names): achieved = algorithmic bytes of one launch (SURVEY.md 8d:
 2*B*C*H*W*4 read + B*441*H*W*4 written = 93 683 712 B) / mean launch duration, measured with HIP
-events on the launch stream inside the timed steps.  `cpu_baseline` times the CPU oracle
+events on the launch stream in a second pass over the same K steps (the timed region itself carries no
+per-op events: they cost 10 % of a 0.37 ms step).  `cpu_baseline` times the CPU oracle
 (oracle/, a restatement of the reference kernels; the reference itself has no CPU path) on a
 bounded sample of the same workload on the host cores.
 """
@@ -177,6 +178,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay a hipGraph of the step instead of launching it eagerly")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     args = ap.parse_args()
 
@@ -197,17 +199,45 @@ def main():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
 
-    events = {}
+    # The step is seven short launches (0.35 ms of kernels).  The timed region launches them eagerly WITHOUT per-op
+    # events (twelve event records per step cost 40 us); --graph replays a hipGraph of the step instead (measured
+    # slower than eager launches on ROCm 7.2: 0.389 vs 0.372 ms).
+    graph = None
+    if args.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                hp.step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as exc:   # capture unsupported on this stack: say so and time eager launches
+            print(f"[bench] hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr, flush=True)
+            graph = None
+            torch.cuda.synchronize()
+
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        hp.step(events)
+        if graph is not None:
+            graph.replay()
+        else:
+            hp.step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = dist_utils.max_over_ranks(elapsed, device=dev)   # the step time is the slowest rank's
+
+    # Per-kernel durations: the same K steps once more with a HIP event pair around every op on the launch stream
+    # (same kernels, same inputs; rocprofv3's per-kernel averages of this command agree).
+    events = {}
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.step(events)
+    torch.cuda.synchronize()
+    eager_elapsed = time.perf_counter() - t1
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
@@ -243,6 +273,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "launch": "hipGraph replay of the step" if graph is not None else "eager launches",
+            "ms_per_step_eager_with_events": round(eager_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
