@@ -63,10 +63,13 @@ extern "C" int fn2_correlation_forward_fused(const void *in1, const void *in2, v
                          (out_batch_stride % 2 == 0);
     const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || algo >= 100);
     if (wants_mfma && !mfma_ok) return FN2_EUNSUPPORTED;
-    if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok))
-        return corr_forward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
-                                     static_cast<float *>(out), p.out_bs, p.slope, B, C, H, W, max_displacement,
-                                     algo, s); // 0 auto, 2 fp32 MFMA, 3 bf16x3, >= 100 profiling instantiations
+    if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok)) {
+        rc = corr_forward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
+                                   static_cast<float *>(out), p.out_bs, p.slope, B, C, H, W, max_displacement,
+                                   algo, s); // 0 auto, 2 fp32 MFMA, 3 bf16x3, >= 100 profiling instantiations
+        // automatic selection: a shape the tiled kernels decline (nothing launched) goes to the general kernel
+        if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
+    }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_forward_direct(in1, in2, out, dtype, p, s);
 }
@@ -122,9 +125,10 @@ extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, con
         // internal tune: 0 = automatic (bf16x3 where its extra preconditions hold), 6 = fp32 MFMA, 4 = bf16x3 or
         // FN2_EUNSUPPORTED, algo - 100 = profiling variants
         const int tune = algo == FN2_CORR_MFMA_F32 ? 6 : algo == FN2_CORR_MFMA_BF16X3 ? 4 : algo >= 100 ? algo - 100 : 0;
-        return corr_backward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
-                                      static_cast<const float *>(grad_out), static_cast<float *>(grad_in1),
-                                      static_cast<float *>(grad_in2), B, C, H, W, max_displacement, tune, s);
+        rc = corr_backward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
+                                    static_cast<const float *>(grad_out), static_cast<float *>(grad_in1),
+                                    static_cast<float *>(grad_in2), B, C, H, W, max_displacement, tune, s);
+        if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
     }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_backward_direct(in1, in2, grad_out, grad_in1, grad_in2, dtype, p, s);

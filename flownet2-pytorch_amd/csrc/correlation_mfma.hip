@@ -83,12 +83,14 @@ struct Cfg {
 // D layout of v_mfma_f32_16x16x4_f32: lane l, register r holds D[row = 4*(l>>4) + r][col = l&15];
 // rows are A pixels (ai = row>>2 = l>>4, aj = row&3 = r), columns B pixels (bi = fi>>2, bj = fi&3).
 // The caller guarantees that every wave has finished reading the operand buffers that alias `smem`.
-template <int NV, int EP, int VAR>
-__device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Args &p, int lane, int wave, int n,
+// NAB A blocks per wave, NW = 16 / NAB waves per workgroup (wave = (x parity, group of NAB A column blocks))
+template <int NV, int EP, int VAR, int NAB = 2>
+__device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[NAB][NV], const Args &p, int lane, int wave, int n,
                                          int py, int rg, int u, int X0, int HL, long HW)
 {
+    constexpr int NW = 16 / NAB;
     const int xpar = wave & 1;
-    const int a0 = (wave >> 1) << 1;
+    const int a0 = (wave >> 1) * NAB;
     const int fi = lane & 15, fq = lane >> 4;
     {
         float *Os = smem;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
             const bool mine = (EP == 1) || ((e_ai / AI_PER_PASS) == pass);
             const int plane = ((e_ai % AI_PER_PASS) * 4 + e_bi) * p.D;
 #pragma unroll
-            for (int ab = 0; ab < 2; ++ab)
+            for (int ab = 0; ab < NAB; ++ab)
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -123,7 +125,7 @@ __device__ __forceinline__ void epilogue(float *smem, f4 (&acc)[2][NV], const Ar
             __syncthreads();
             // each wave writes whole planes: rows (plane, ti) for ti = 0..D-1, two rows per instruction,
             // 8 B per lane -> one 256 B contiguous segment per row
-            for (int pl = wave; pl < 4 * AI_PER_PASS; pl += 8) {
+            for (int pl = wave; pl < 4 * AI_PER_PASS; pl += NW) {
                 const int ai = pass * AI_PER_PASS + (pl >> 2), bi = pl & 3;
                 const int tj = 4 * u + bi - ai;
                 const int IL = 4 * rg + ai;
@@ -594,9 +596,13 @@ constexpr int SB_STAGE = 2 * SB_TILE;      // 16640 floats = 66 560 B
 
 // NST = 2: two-stage ring, one workgroup per CU (133 KB).  NST = 1: one stage (66 KB, two-pass epilogue), two
 // workgroups per CU -- the other workgroup's vector work covers this one's DMA latency and store drain.
-template <int NV, int EP, int VAR, int NST = 2>
-__global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(Args p)
+// NAB = 2: 8 waves of two A blocks (7 B fragments for 12 block pairs).  NAB = 4: 4 waves of four A blocks (9 B fragments
+// for 24 pairs: 28 % less operand-split work per MFMA), 256 VGPRs per wave, still two workgroups per CU with NST = 1.
+template <int NV, int EP, int VAR, int NST = 2, int NAB = 2>
+__global__ __launch_bounds__(64 * (16 / NAB), (NST == 1 ? (NAB == 2 ? 4 : 2) : (NAB == 2 ? 2 : 1))) void corr_fwd_mfma_bf16x3(Args p)
 {
+    constexpr int NW = 16 / NAB, NT = 64 * NW, NBF = NV + NAB - 1;   // waves, threads, B fragments per wave
+    constexpr int CPW = SB_CK / NW;                                   // channels staged per wave and stage
     constexpr int O_FLOATS = (16 / EP) * (2 * DR_MAX + 1) * O_RS + 64;
     constexpr int LDS_FLOATS = (NST * SB_STAGE > O_FLOATS) ? NST * SB_STAGE : O_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
@@ -619,23 +625,24 @@ __global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(
     const float *in2n = p.in2 + (long)n * p.C * HW;
     const int X0 = xt * TILE_X;
 
-    // ---- DMA roles: wave w stages channels 4w..4w+3 of a stage, one instruction per (channel, tile):
-    // lane = (row, slot); slot holds piece (slot - 2 row - 4 ((c>>3)&1)) mod 16 of the row, c>>3 == w>>1.
+    // ---- DMA roles: wave w stages channels CPW*w .. CPW*w + CPW-1 of a stage, one instruction per (channel, tile):
+    // lane = (row, slot); slot holds piece (slot - 2 row - 4 ((c>>3)&1)) mod 16 of the row; c>>3 is constant per wave
+    // (CPW divides 8).
     const int d_row = lane >> 4, d_slot = lane & 15;
-    const int d_piece = (d_slot - 2 * d_row - 4 * ((wave >> 1) & 1)) & 15;
+    const int d_piece = (d_slot - 2 * d_row - 4 * (((CPW * wave) >> 3) & 1)) & 15;
     const int d_x = X0 + 4 * d_piece;
     const int d_ila = 4 * rg + d_row, d_ilb = ib0 + d_row;
     const bool d_oka = (d_ila < HL) && (d_x < p.W);
     const bool d_okb = (d_ilb >= 0) && (d_ilb < HL) && (d_x < p.W);
     const int d_offa = (2 * d_ila + py) * p.W + d_x;
     const int d_offb = (2 * d_ilb + py) * p.W + d_x;
-    const int n_dma = 4 * ((__ballot(d_oka) != 0ull ? 1 : 0) + (__ballot(d_okb) != 0ull ? 1 : 0));
+    const int n_dma = CPW * ((__ballot(d_oka) != 0ull ? 1 : 0) + (__ballot(d_okb) != 0ull ? 1 : 0));
     auto dma_issue = [&](int c0, int stage) {
         if (VAR & 2) return;
         float *st = smem + stage * SB_STAGE;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * wave + k;
+        for (int k = 0; k < CPW; ++k) {
+            const int c = CPW * wave + k;
             if (d_oka)
                 __builtin_amdgcn_global_load_lds(in1n + (long)(c0 + c) * HW + d_offa,
                                                  (__attribute__((address_space(3))) void *)(st + c * SB_CH), 16, 0, 0);
@@ -645,32 +652,32 @@ __global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(
         }
     };
     auto wait_all_but = [&](int chunks) {   // at most `chunks` x n_dma DMAs of this wave still in flight
-        if (chunks == 0 || n_dma == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (chunks == 0 || n_dma == 0 || CPW != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (n_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
 
     // ---- MFMA roles
     const int xpar = wave & 1;
-    const int a0 = (wave >> 1) << 1;
+    const int a0 = (wave >> 1) * NAB;
     const int fi = lane & 15, fq = lane >> 4;
     const int f_row = fi >> 2, f_col = fi & 3;
     const int rot = 8 * f_row + 16 * (fq & 1);
-    int a_frag[2];
+    int a_frag[NAB];
 #pragma unroll
-    for (int ab = 0; ab < 2; ++ab)
+    for (int ab = 0; ab < NAB; ++ab)
         a_frag[ab] = (8 * fq) * SB_CH + f_row * 64 + ((2 * (4 * (a0 + ab) + f_col) + xpar + rot) & 63);
-    int b_frag[NV + 1];
+    int b_frag[NBF];
 #pragma unroll
-    for (int j = 0; j < NV + 1; ++j) {
+    for (int j = 0; j < NBF; ++j) {
         const int x = 2 * (4 * (a0 + j) + f_col - p.dr) + xpar;          // tile-local image x of this lane's B pixel
         const bool in_img = (x >= 0) && (X0 + x < p.W) && (x < TILE_X);
         b_frag[j] = SB_TILE + (8 * fq) * SB_CH + (in_img ? f_row * 64 + ((x + rot) & 63) : 256);   // 256: the zero pad
     }
 
-    f4 acc[2][NV];
+    f4 acc[NAB][NV];
 #pragma unroll
-    for (int ab = 0; ab < 2; ++ab)
+    for (int ab = 0; ab < NAB; ++ab)
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[ab][v] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -682,33 +689,33 @@ __global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(
         // previous fragment's VALU + MFMA work); order: A[0], A[1], B[0], B[1], ...
         float rq[2][8];
         auto fetch = [&](int f, float (&r)[8]) {
-            const int base = (f < 2) ? a_frag[f] : b_frag[f - 2];
+            const int base = (f < NAB) ? a_frag[f < NAB ? f : 0] : b_frag[f < NAB ? 0 : f - NAB];
 #pragma unroll
             for (int k = 0; k < 8; ++k) r[k] = st[base + k * SB_CH];
         };
-        u4 A0[2], A1[2], A2[2];
+        u4 A0[NAB], A1[NAB], A2[NAB];
         fetch(0, rq[0]);
 #pragma unroll
-        for (int f = 0; f < NV + 3; ++f) {
+        for (int f = 0; f < NAB + NBF; ++f) {
             const int cur = f & 1;
-            if (f + 1 < NV + 3) fetch(f + 1, rq[cur ^ 1]);
+            if (f + 1 < NAB + NBF) fetch(f + 1, rq[cur ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (f < 2) {
+            if (f < NAB) {
                 split3(rq[cur], A0[f], A1[f], A2[f]);
                 if (VAR & 1) asm volatile("" ::"v"(A0[f][0]), "v"(A1[f][0]), "v"(A2[f][0]), "v"(A0[f][3]), "v"(A1[f][3]), "v"(A2[f][3]));
             } else {
-                const int j = f - 2;
+                const int j = f - NAB;
                 u4 B0, B1, B2;
                 split3(rq[cur], B0, B1, B2);
                 if (!(VAR & 1)) {
-                    // six products per pair; the two pairs of this B block (ab = 0: v = j, ab = 1: v = j-1) alternate
-                    // so that consecutive MFMAs never wait on the same accumulator
+                    // six products per pair; the pairs of this B block (A block ab: v = j - ab) alternate so that
+                    // consecutive MFMAs never wait on the same accumulator
                     const u4 *PA[6] = {A0, A0, A1, A1, A0, A2};
                     const u4 *PB[6] = {&B0, &B1, &B0, &B1, &B2, &B0};
 #pragma unroll
                     for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-                        for (int ab = 0; ab < 2; ++ab) {
+                        for (int ab = 0; ab < NAB; ++ab) {
                             const int v = j - ab;
                             if (v >= 0 && v < NV)
                                 acc[ab][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(PA[pr][ab]), as_bf(*PB[pr]), acc[ab][v], 0, 0, 0);
@@ -722,9 +729,9 @@ __global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(
     };
 
     const int nsteps = all_pad ? 0 : p.C / SB_CK;
-    const bool early = (wave < 4);    // waves w and w+4 share a SIMD: complementary DMA / MFMA phases
+    const bool early = (wave < NW / 2);    // waves w and w+4 share a SIMD: complementary DMA / MFMA phases
     if (nsteps > 0) {
-        for (int i = tid; i < NST * SB_STAGE / 4; i += 512) reinterpret_cast<f4 *>(smem)[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = tid; i < NST * SB_STAGE / 4; i += NT) reinterpret_cast<f4 *>(smem)[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
         dma_issue(0, 0);
         for (int sk = 0; sk < nsteps; ++sk) {
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(512, (NST == 1 ? 4 : 2)) void corr_fwd_mfma_bf16x3(
         }
         __syncthreads();
     }
-    epilogue<NV, EP, VAR>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
+    epilogue<NV, EP, VAR, NAB>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
 }
 
 } // namespace mf
@@ -829,6 +836,13 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, long o
         case 2002: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 2>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2100: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 0, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2101: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 1, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2200: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 0, 1, 4>), dim3((unsigned)ntasks), dim3(256), 0, s, a); return launch_status();
+        case 2201: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 1, 1, 4>), dim3((unsigned)ntasks), dim3(256), 0, s, a); return launch_status();
+        case 2210: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 0, 2, 4>), dim3((unsigned)ntasks), dim3(256), 0, s, a); return launch_status();
+        case 2102: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 2, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2104: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 4, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2106: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 6, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 2107: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 7, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2004: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 4>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2007: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 7>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         default: return FN2_EUNSUPPORTED;
