@@ -20,3 +20,5 @@ ROOTDIR=$(pwd)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof_bench -- python $ROOTDIR/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOTDIR/$OUT/prof_bench.log 2>&1 )
 find $OUT/prof_bench -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof_bench -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -20 "$f"
+# fused "next" rows and the backward kernels' L2 traffic (cheap; skipped if the scripts are missing)
+[ -f scripts/next_rows_micro.py ] && python scripts/next_rows_micro.py 2>/dev/null | tail -1 > $OUT/next_rows.json && cat $OUT/next_rows.json
