@@ -332,6 +332,8 @@ template <int TX> struct BT {
 };
 __device__ __attribute__((aligned(16))) const float kZeroBlock[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
+// VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no neighbour DMA, 4 no G DMA, 8 no stores, 16 neighbour DMA
+// before the G part, 128 s_memtime stamps of one phase dumped over gradInput1, 256 no s_setprio around the DMA issue
 template <int TX, int NV, int NCT, int VAR = 0>
 __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
 {
@@ -513,7 +515,8 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
                 // DMAs of this phase: the neighbour tile of the next phase (already out for ct = 0) and part ct of the
                 // next u's G tile
                 stamp(2, tu && ct == 1);
-                // (G part first and raised wave priority while issuing: 186 -> 173 us; VAR 16 / 256 switch them off)
+                // (G part first and raised wave priority while issuing; VAR 16 / 256 switch them off -- differences are
+                // within the run-to-run noise of a few us)
                 if (!(VAR & 256)) __builtin_amdgcn_s_setprio(3);
                 if (!(VAR & 16) && next_u) g_dma(u + 1, ct);
                 if (ct > 0 && more) nbr_dma(last_ct ? u + 1 : u, last_ct ? 0 : ct + 1, buf ^ 1);
@@ -525,14 +528,10 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
                 // a slot needs blocks 2sl .. 2sl+2, block 2sl+2 is kept for the next slot (sliding window keeps the
                 // live set small: the G fragments already hold 72 registers)
                 auto frag = [&](int b, u2 &h0, u2 &h1, u2 &h2) __attribute__((always_inline)) {
-                    f4 v0, v1;
-                    if (VAR & 32) { v0 = (f4){(float)lane, (float)b, (float)u, 1.0f}; v1 = v0 + 1.0f; asm volatile("" : "+v"(v0), "+v"(v1)); }   // profiling: no LDS reads
-                    else { v0 = *reinterpret_cast<const f4 *>(N + 8 * b); v1 = *reinterpret_cast<const f4 *>(N + 8 * b + 4); }
+                    const f4 v0 = *reinterpret_cast<const f4 *>(N + 8 * b), v1 = *reinterpret_cast<const f4 *>(N + 8 * b + 4);
                     // the wave's x parity selects elements (par, par + 2) of each 16 B piece
                     const float r[4] = {xpar ? v0[1] : v0[0], xpar ? v0[3] : v0[2], xpar ? v1[1] : v1[0], xpar ? v1[3] : v1[2]};
-                    if (VAR & 64) {   // profiling: no split arithmetic
-                        h0 = (u2){__float_as_uint(r[0]), __float_as_uint(r[1])}; h1 = (u2){__float_as_uint(r[2]), __float_as_uint(r[3])}; h2 = h0;
-                    } else split3_half(r, h0, h1, h2);
+                    split3_half(r, h0, h1, h2);
                 };
                 u2 hb[3][3];   // [term][block 2sl + 0..2]
                 frag(0, hb[0][0], hb[1][0], hb[2][0]);
