@@ -559,3 +559,87 @@ def test_wrappers_autograd(dev, oracle):
     gf = wn[:, 9:11] / 20.0 + gflow_o
     assert max_abs(xd.grad.cpu().numpy(), gx) <= TOL
     assert max_abs(fd.grad.cpu().numpy(), gf) <= TOL
+
+
+def _fuzz_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        md = int(rng.choice([2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 21]))
+        C = int(rng.choice([1, 3, 16, 32, 48, 64, 128]))
+        H = int(rng.integers(2, 27))
+        W = int(rng.integers(2, 75))
+        if rng.random() < 0.6:       # bias towards the tiled kernels' domain
+            H += H & 1
+            W += (-W) % 4
+            C = max(16, C - C % 16)
+        cases.append((int(rng.integers(1, 4)), C, H, W, md))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(2024, 36))
+def test_correlation_fuzz_vs_oracle(dev, oracle, case):
+    """Seeded random shapes through the automatic dispatch (tiled MFMA kernels where they apply, the general kernel
+    otherwise), forward, fused forward and backward against the oracle."""
+    import fn2_capi
+    B, C, H, W, md = case
+    rng = np.random.default_rng(hash(case) % (1 << 31))
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    D2 = (2 * (md // 2) + 1) ** 2
+    go = rng.standard_normal((B, D2, H, W)).astype(np.float32)
+    ad, bd, gd = to_dev(a, dev), to_dev(b, dev), to_dev(go, dev)
+    ref = oracle.corr_fwd(a, b, md, 1, md, 1, 2)
+    out = torch.full((B, D2, H, W), float("nan"), device=dev)
+    fn2_capi.correlation_forward(ad, bd, md, 1, md, 1, 2, out=out)
+    assert max_abs(out.cpu().numpy(), ref) <= 2e-6
+    buf = torch.full((B, D2 + 2, H, W), float("nan"), device=dev)
+    fn2_capi.correlation_forward_fused(ad, bd, buf, 1, 0.1, md, 1, md, 1, 2)
+    lref = np.where(ref > 0, ref, ref * np.float32(0.1))
+    assert max_abs(buf[:, 1:1 + D2].cpu().numpy(), lref) <= 2e-6
+    assert torch.isnan(buf[:, 0]).all() and torch.isnan(buf[:, 1 + D2]).all()
+    r1, r2 = oracle.corr_bwd(a, b, go, md, 1, md, 1, 2)
+    g1 = torch.full((B, C, H, W), float("nan"), device=dev)
+    g2 = torch.full((B, C, H, W), float("nan"), device=dev)
+    fn2_capi.correlation_backward(ad, bd, gd, md, 1, md, 1, 2, out=(g1, g2))
+    scale = max(1.0, float(np.abs(r1).max()), float(np.abs(r2).max()))
+    assert max_abs(g1.cpu().numpy(), r1) <= 5e-6 * scale and max_abs(g2.cpu().numpy(), r2) <= 5e-6 * scale
+
+
+def _fuzz_img_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 70)), int(rng.integers(1, 150)),
+             bool(rng.integers(0, 2))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _fuzz_img_cases(7, 24))
+def test_resample_channelnorm_fuzz_vs_oracle(dev, oracle, case):
+    """Seeded random image shapes (tiled and untiled kernels, W % 4 != 0, single rows/columns): Resample2d forward and
+    backward, ChannelNorm forward and backward, and the fused warp-diff-norm-cat row against the oracle."""
+    import fn2_capi
+    from networks.resample2d_package.resample2d import Resample2dFunction
+    from networks.channelnorm_package.channelnorm import ChannelNormFunction
+    B, C, H, W, bilinear = case
+    rng = np.random.default_rng(hash(case) % (1 << 31))
+    img = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    flow = (rng.standard_normal((B, 2, H, W)) * 3.0).astype(np.float32)
+    flow.reshape(-1)[rng.integers(0, flow.size, max(1, flow.size // 50))] *= 30.0
+    gout = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    imd = to_dev(img, dev).requires_grad_(True)
+    fld = to_dev(flow, dev).requires_grad_(True)
+    out = Resample2dFunction.apply(imd, fld, 1, bilinear)
+    ref = oracle.resample_fwd(img, flow, 1, bilinear)
+    assert max_abs(out.detach().cpu().numpy(), ref) <= TOL
+    out.backward(to_dev(gout, dev))
+    rgi, rgf = oracle.resample_bwd(img, flow, gout, 1, bilinear)
+    s = max(1.0, float(np.abs(rgi).max()), float(np.abs(rgf).max()))
+    assert max_abs(imd.grad.cpu().numpy(), rgi) <= 1e-5 * s
+    assert max_abs(fld.grad.cpu().numpy(), rgf) <= 1e-5 * s
+    x = to_dev(img, dev).requires_grad_(True)
+    nrm = ChannelNormFunction.apply(x, 2)
+    assert max_abs(nrm.detach().cpu().numpy(), oracle.chnorm_fwd(img)) <= 1e-6 * max(1.0, float(np.abs(img).max()) * C)
+    pair = rng.standard_normal((B, 2 * C, H, W)).astype(np.float32)
+    got = fn2_capi.warp_diff_norm_cat(to_dev(pair, dev), to_dev(flow, dev), 20.0, bilinear).cpu().numpy()
+    warped = oracle.resample_fwd(np.ascontiguousarray(pair[:, C:]), flow, 1, bilinear)
+    refc = np.concatenate((pair, warped, flow * (np.float32(1.0) / np.float32(20.0)), oracle.chnorm_fwd(pair[:, :C] - warped)), axis=1)
+    assert max_abs(got, refc) <= TOL
