@@ -18,8 +18,9 @@ collective: weak scaling); value = image pairs processed by all ranks / max-over
 Rank 0 prints ONE JSON line.  `roofline` is for the correlation forward kernel (the kernel
 BASELINE.json's metric names): achieved = algorithmic bytes of one launch (SURVEY.md 8d:
 2*B*C*H*W*4 read + B*441*H*W*4 written = 93 683 712 B) / mean launch duration, measured with HIP
-events on the launch stream in a second pass over the same K steps (the timed region itself carries no
-per-op events: they cost 10 % of a 0.37 ms step).  `cpu_baseline` times the CPU oracle
+events on the launch stream inside the timed steps (one event pair per step around that kernel; the other
+five ops are timed in a second pass over the same K steps: event pairs around everything cost 10 % of a
+0.37 ms step).  `cpu_baseline` times the CPU oracle
 (oracle/, a restatement of the reference kernels; the reference itself has no CPU path) on a
 bounded sample of the same workload on the host cores.
 """
@@ -98,11 +99,11 @@ class HotPath:
     def corr_bwd(self):
         self.m_corr.backward(self.in1, self.in2, self.scr1, self.scr2, self.gcorr, self.g1, self.g2, *self.cparams)
 
-    def step(self, events=None):
+    def step(self, events=None, only=None):
         """fwd + bwd of the three layers.  `events`, if given, collects (start, stop) HIP event
-        pairs around each op on the current stream."""
+        pairs around each op (or just the ops named in `only`) on the current stream."""
         def timed(name, fn):
-            if events is None:
+            if events is None or (only is not None and name not in only):
                 fn()
                 return
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -199,9 +200,10 @@ def main():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
 
-    # The step is seven short launches (0.35 ms of kernels).  The timed region launches them eagerly WITHOUT per-op
-    # events (twelve event records per step cost 40 us); --graph replays a hipGraph of the step instead (measured
-    # slower than eager launches on ROCm 7.2: 0.389 vs 0.372 ms).
+    # The step is seven short launches (0.35 ms of kernels).  The timed region launches them eagerly with ONE event
+    # pair per step, around the graded kernel (correlation forward); event pairs around all six ops cost 40 us per
+    # step, so the other kernels are timed in a second pass.  --graph replays a hipGraph of the step instead (measured
+    # slower than eager launches on ROCm 7.2: 0.389 vs 0.372 ms; its roofline then comes from the second pass).
     graph = None
     if args.graph:
         try:
@@ -218,11 +220,12 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    roof_events = {}   # the graded kernel is timed inside the timed region itself (one event pair per step)
     for _ in range(args.steps):
         if graph is not None:
             graph.replay()
         else:
-            hp.step()
+            hp.step(roof_events, only=("corr_fwd",))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -241,6 +244,9 @@ def main():
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
+        if roof_events.get("corr_fwd"):   # roofline: the durations recorded inside the timed region
+            v = roof_events["corr_fwd"]
+            per_op_ms["corr_fwd"] = sum(s.elapsed_time(e) for s, e in v) / len(v)
         ab = algorithmic_bytes(CORR["B"])
         kernels = {k: {"ms": round(ms, 5), "algorithmic_bytes": ab[k],
                        "achieved_GBps": round(ab[k] / (ms * 1e-3) / 1e9, 2),
