@@ -308,6 +308,17 @@ def main():
                 "launch_ms": cf["ms"],
                 "algorithmic_bytes": cf["algorithmic_bytes"],
             },
+            # the same kernel against the matrix-core roof: it issues 6 bf16 MFMAs (exact 3-term operand split) per 16x16x32
+            # block product over the 6x6 neighbour blocks of every 4x4 pixel block (76.6 % of them inside the 21x21 band)
+            "roofline_mfma": (lambda mfma_flop: {
+                "kernel": "correlation forward (corr_fwd_mfma_bf16x3)", "bound": "mfma",
+                "achieved": round(mfma_flop / (cf["ms"] * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(mfma_flop / (cf["ms"] * 1e-3) / 1e12 / 2500.0, 4),
+                "issued_bf16_flop_per_launch": mfma_flop,
+                "useful_fp32_flop_per_launch": 2 * CORR["B"] * CORR["H"] * CORR["W"] * 441 * CORR["C"],
+                "note": "issued = useful x 6 (products of the split) / 0.766 (band); the split itself is VALU work that "
+                        "does not overlap with MFMA issue on a SIMD (DESIGN.md 4.1)"})(
+                6 * 2 * CORR["B"] * CORR["H"] * CORR["W"] * 576 * CORR["C"]),
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
