@@ -728,6 +728,9 @@ __global__ __launch_bounds__(64 * (16 / NAB), (NST == 1 ? (NAB == 2 ? 4 : 2) : (
         }
     };
 
+    // VAR 1024 (profiling): s_memtime stamps of step 3 and of the epilogue, dumped over the start of the output
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i, bool on) __attribute__((always_inline)) { if ((VAR & 1024) && on) ts[i] = __builtin_amdgcn_s_memtime(); };
     const int nsteps = all_pad ? 0 : p.C / SB_CK;
     const bool early = (wave < NW / 2);    // waves w and w+4 share a SIMD: complementary DMA / MFMA phases
     if (nsteps > 0) {
@@ -737,8 +740,11 @@ __global__ __launch_bounds__(64 * (16 / NAB), (NST == 1 ? (NAB == 2 ? 4 : 2) : (
         for (int sk = 0; sk < nsteps; ++sk) {
             // early waves have issued step sk only; late waves have issued step sk only as well (they issue
             // step sk+1 at the end of this iteration): wait for everything
+            stamp(0, sk == 3);
             wait_all_but(0);
+            stamp(1, sk == 3);
             __builtin_amdgcn_s_barrier();   // step sk is visible to all; the other stage is free
+            stamp(2, sk == 3);
             const bool more = (sk + 1 < nsteps);
             if (NST == 2) {
                 if (more && early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
@@ -746,16 +752,31 @@ __global__ __launch_bounds__(64 * (16 / NAB), (NST == 1 ? (NAB == 2 ? 4 : 2) : (
                 if (more && !early) dma_issue((sk + 1) * SB_CK, (sk + 1) & 1);
             } else {
                 mma_step(0);
+                stamp(3, sk == 3);
                 if (more) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();   // every wave has read the stage: refill it
+                    stamp(4, sk == 3);
                     dma_issue((sk + 1) * SB_CK, 0);
+                    stamp(5, sk == 3);
                 }
             }
         }
         __syncthreads();
     }
+    stamp(6, true);
     epilogue<NV, EP, VAR, NAB>(smem, acc, p, lane, wave, n, py, rg, u, X0, HL, HW);
+    stamp(7, true);
+    if ((VAR & 1024) && lane == 0) {   // one non-padding task of each dispatch round on what should be the same CU
+        int slot = -1;
+        if (blockIdx.x == 8 * 27 + 2) slot = 0;
+        if (blockIdx.x == 8 * 27 + 2 + 256) slot = 1;
+        if (slot >= 0) {
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(p.out) + (slot * 8 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = ts[i];
+        }
+    }
 }
 
 } // namespace mf
@@ -843,6 +864,7 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, long o
         case 2104: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 4, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2106: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 6, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2107: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 7, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+        case 3124: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 2, 1024, 1>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2004: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 4>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         case 2007: if (a.NXT != 1 || C % 32) return FN2_EUNSUPPORTED; hipLaunchKernelGGL((mf::corr_fwd_mfma_bf16x3<6, 1, 7>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
         default: return FN2_EUNSUPPORTED;

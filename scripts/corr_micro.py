@@ -52,6 +52,13 @@ for algo in (int(v) for v in a.algos.split(",")):
         r["max_abs_vs_direct"] = float((out - ref).abs().max())
     res[algo] = r
     print(algo, r, flush=True)
+    if algo == 3124:   # instrumented forward: s_memtime stamps of two workgroups (dispatch rounds 0 and 1 of one CU)
+        torch.cuda.synchronize()
+        st = out.view(-1)[:256].view(torch.int64).cpu().view(2, 8, 8)
+        t0 = int(st[st > 0].min())
+        for sl in range(2):
+            for w in range(8):
+                print("   wg", sl, "wave", w, [int(v) - t0 if v > 0 else None for v in st[sl, w]])
 if a.bwd:
     gout = torch.randn(B, D * D, H, W, generator=g).to(dev)
     refb = None
