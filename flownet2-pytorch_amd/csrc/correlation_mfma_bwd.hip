@@ -353,6 +353,8 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // (Visiting the row groups from the middle outwards inside every XCD's share -- longest tasks first -- measured no
+    // difference here; the forward kernel does gain from dispatching its all-padding tasks last.)
     unsigned t = xcd_remap(blockIdx.x, gridDim.x);
     const int cg = (int)(t % p.NCG); t /= p.NCG;
     const int xt = (int)(t % p.NXT); t /= p.NXT;
