@@ -260,6 +260,13 @@ def main():
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        # what an event pair adds around ONE short kernel (launch latency + inter-packet gaps): a 4-byte fill
+        tiny = torch.zeros(1, device=dev)
+        nev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for s_, e_ in nev:
+            s_.record(); tiny.zero_(); e_.record()
+        torch.cuda.synchronize()
+        event_floor_ms = sorted(s_.elapsed_time(e_) for s_, e_ in nev)[len(nev) // 2]
         pairs = CORR["B"] * args.steps * world
         # empirical streaming ceiling of this box: device-to-device copy of 1 GiB, read + write bytes
         src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
@@ -306,6 +313,8 @@ def main():
                 "traffic": traffic,
                 "copy_ceiling_GBps": round(copy_gbs, 1),
                 "launch_ms": cf["ms"],
+                "event_pair_floor_ms": round(event_floor_ms, 5),   # the same event pair around a 4-byte fill: rocprofv3's kernel
+                                                                  # durations are shorter than launch_ms by about this much
                 "algorithmic_bytes": cf["algorithmic_bytes"],
             },
             # the same kernel against the matrix-core roof: it issues 6 bf16 MFMAs (exact 3-term operand split) per 16x16x32
