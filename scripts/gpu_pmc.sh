@@ -6,14 +6,14 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp; R=$(pwd)
 ALGO=${ALGO:-2}
-G1="TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum"
+# (TA_* counters are NOT collected: a pass with TA_BUSY_avr / TA_*_STALLED_* hung rocprofv3 on this pool until the gpurun limit)
 G2="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum"
 G3="TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_BUSY_avr"
 G4="SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 G5="FETCH_SIZE"
 G6="WRITE_SIZE GRBM_GUI_ACTIVE"
 i=0
-for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6"; do
+for G in "$G2" "$G3" "$G4" "$G5" "$G6"; do
   i=$((i+1))
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/$OUT/pmc_${ALGO}_$i -- python $R/scripts/corr_micro.py --algos $ALGO --iters 5 > $R/$OUT/pmc_${ALGO}_$i.log 2>&1 )
   f=$(find $OUT/pmc_${ALGO}_$i -name "*counter_collection.csv" | head -1)
