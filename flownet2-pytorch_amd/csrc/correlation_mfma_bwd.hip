@@ -401,14 +401,31 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
     // ti of one plane (lane = (ti % RG, piece)), contiguous in LDS: Gs[plane*GP + ti*TX + x].  Wave w takes planes
     // w, w+NW, ..: 12 instructions per u, issued in NCT parts.  FLIP: the source row is shifted by 2(ti-dr) pixels; a piece that
     // straddles the image edge is fetched from the clamped position and the fragment read below compensates.
+    // Per DMA the source is go_n + A(plane, u) + L[g]: A is wave-uniform (scalar arithmetic), L[g] the lane's part -- it does
+    // not depend on u and is formed once per group g (-1: the lane's piece lies outside the image and reads zeros).  Keeping
+    // the issue path to a handful of instructions matters: a phase issues 11 DMAs per wave, all waves at the same time.
     constexpr int GI = 12 / NCT;
+    int g_lane[T::NGRP];
+    {
+        const int r = lane / T::PPR, x = X0 + 4 * (lane % T::PPR);
+#pragma unroll
+        for (int g = 0; g < T::NGRP; ++g) {
+            const int ti = T::RG * g + r;
+            if (!FLIP) g_lane[g] = (x < p.W && ti < p.D) ? ti * HWi + x : -1;
+            else {
+                // G'[tj', ti'][p] = gO[(2dr - tj')*D + (2dr - ti')][p + 2d'],  d' = (tj'-dr, ti'-dr): -ti' rows, x shifted
+                const int xs = x + 2 * (ti - p.dr);
+                g_lane[g] = (x < p.W && ti < p.D && xs >= -2 && xs <= p.W - 2) ? (p.D - 1 - ti) * HWi + min(max(xs, 0), p.W - 4) : -1;
+            }
+        }
+    }
+    const int g_rows_last = (2 * DR_MAX + 1) - T::RG * (T::NGRP - 1);   // ti rows of the last group that exist in the LDS tile
     auto g_dma = [&](int u, int pt) __attribute__((always_inline)) {
         if (VAR & 4) return;
         // opaque copies: the row addresses are cheap scalar arithmetic; left to the optimiser they are all hoisted out
         // of the u loop (hundreds of SGPRs, spilled)
         int D_ = p.D, HWi_ = HWi;
         asm volatile("" : "+s"(D_), "+s"(HWi_));
-        const int r = lane / T::PPR, x = X0 + 4 * (lane % T::PPR);
 #pragma unroll
         for (int jj = 0; jj < GI; ++jj) {
             const int j = pt * GI + jj, hh = j / T::NGRP, g = j % T::NGRP;
@@ -416,21 +433,16 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
             const int ai = pl >> 2, bi = pl & 3;
             const int tj = 4 * u + bi - ai;          // displacement row index of this plane
             const int IL = 4 * rg + ai;              // centre lattice row
-            const bool row_ok = (tj >= 0) && (tj < D_) && (IL < HL);
-            const int ti = T::RG * g + r;
-            bool ok;
-            int off;
-            if (!FLIP) {
-                ok = row_ok && (x < p.W);
-                off = (tj * D_ + ti) * HWi_ + (2 * IL + py) * p.W + x;
-            } else {
-                // G'[tj', ti'][p] = gO[(2dr - tj')*D + (2dr - ti')][p + 2d'],  d' = (tj'-dr, ti'-dr)
-                const int ys = 2 * IL + py + 2 * (tj - p.dr), xs = x + 2 * (ti - p.dr);
-                ok = row_ok && (ys >= 0) && (ys < p.H) && (xs >= -2) && (xs <= p.W - 2) && (x < p.W);
-                off = ((2 * p.dr - tj) * D_ + (2 * p.dr - ti)) * HWi_ + ys * p.W + min(max(xs, 0), p.W - 4);
-            }
-            const float *src = ok ? go_n + off : zeros;
-            if (ti < D_) __builtin_amdgcn_global_load_lds(src, (lds_ptr)(Gs + pl * GP + g * 256), 16, 0, 0);   // RG rows = 256 floats
+            const int ys = 2 * IL + py + (FLIP ? 2 * (tj - p.dr) : 0);
+            const bool row_ok = (tj >= 0) && (tj < D_) && (IL < HL) && (ys >= 0) && (ys < p.H);
+            // !FLIP: plane tj*D (+ti), row ys;  FLIP: plane (2dr - tj)*D + (2dr - ti) = (D-1-tj)*D + (D-1-ti), row ys
+            const int A = (FLIP ? (D_ - 1 - tj) : tj) * D_ * HWi_ + ys * p.W;
+            const int L = g_lane[g];
+            // one per-lane select, no wave-uniform branch: a negative offset marks "read zeros" (offsets are < 2^31)
+            const int off = (A + L) | (L >> 31) | (row_ok ? 0 : (int)0x80000000);
+            const float *src = off >= 0 ? go_n + off : zeros;
+            if (g + 1 < T::NGRP || lane < g_rows_last * T::PPR)
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(Gs + pl * GP + g * 256), 16, 0, 0);   // RG rows = 256 floats
         }
     };
     // end of a phase: wait for this wave's DMAs and LDS reads, then one raw barrier.  (Leaving the G-tile DMAs in flight
