@@ -20,8 +20,10 @@ __global__ __launch_bounds__(512) void k(float *sink, int iters)
         else if (KIND == 3) {   // float add as a compare-and-swap loop
             unsigned old = wu[a], assumed;
             do { assumed = old; old = atomicCAS(&wu[a], assumed, __float_as_uint(__uint_as_float(assumed) + 1.0f)); } while (old != assumed);
-        } else {                // 64-bit integer add (fixed point), half as many cells
+        } else if (KIND == 4) { // 64-bit integer add (fixed point), half as many cells
             atomicAdd(reinterpret_cast<unsigned long long *>(w) + (a >> 1), 12345ull);
+        } else {                // double add (ds_add_f64), half as many cells
+            atomicAdd(reinterpret_cast<double *>(w) + (a >> 1), 1.0);
         }
     }
     __syncthreads();
@@ -32,8 +34,8 @@ int main()
     float *sink; hipMalloc(&sink, 4096);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 2000;
-    const char *kn[5] = {"ds_add_f32 (no rtn)", "ds_add_u32 (no rtn)", "ds_add_rtn_u32", "f32 add via CAS loop", "ds_add_u64 (no rtn)"};
-    for (int kind = 1; kind < 5; ++kind)
+    const char *kn[6] = {"ds_add_f32 (no rtn)", "ds_add_u32 (no rtn)", "ds_add_rtn_u32", "f32 add via CAS loop", "ds_add_u64 (no rtn)", "ds_add_f64 (no rtn)"};
+    for (int kind = 1; kind < 6; ++kind)
         for (int pat = 0; pat < 2; ++pat) {
             float best = 1e9;
             for (int rep = 0; rep < 4; ++rep) {
@@ -48,6 +50,8 @@ int main()
                 if (kind == 3 && pat == 1) hipLaunchKernelGGL((k<3, 1>), dim3(512), dim3(512), 0, 0, sink, iters);
                 if (kind == 4 && pat == 0) hipLaunchKernelGGL((k<4, 0>), dim3(512), dim3(512), 0, 0, sink, iters);
                 if (kind == 4 && pat == 1) hipLaunchKernelGGL((k<4, 1>), dim3(512), dim3(512), 0, 0, sink, iters);
+                if (kind == 5 && pat == 0) hipLaunchKernelGGL((k<5, 0>), dim3(512), dim3(512), 0, 0, sink, iters);
+                if (kind == 5 && pat == 1) hipLaunchKernelGGL((k<5, 1>), dim3(512), dim3(512), 0, 0, sink, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best) best = ms;
