@@ -1,0 +1,62 @@
+"""Soak test (GPU box): many seeded random shapes through the C ABI against the oracle -- the same checks as
+tests/test_gpu_parity.py's fuzz tests, more cases, time-boxed.  Usage: python scripts/soak_fuzz.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import fn2_capi
+from oracle.oracle import Oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+orc, dev, rng = Oracle(), torch.device("cuda:0"), np.random.default_rng(seed)
+D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+mx = lambda a, b: float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.asarray(a).size else 0.0
+t0, ncorr, nimg, worst = time.time(), 0, 0, {}
+def note(k, v): worst[k] = max(worst.get(k, 0.0), v)
+while time.time() - t0 < budget:
+    if rng.random() < 0.6:
+        md = int(rng.choice([2, 4, 8, 10, 12, 16, 18, 20, 20, 20, 21]))
+        C = int(rng.choice([1, 5, 16, 32, 64, 64, 128, 192]))
+        H, W, B = int(rng.integers(2, 40)), int(rng.integers(2, 140)), int(rng.integers(1, 4))
+        if rng.random() < 0.7: H += H & 1; W += (-W) % 4; C = max(16, C - C % 16)
+        a = rng.standard_normal((B, C, H, W)).astype(np.float32) * np.float32(rng.choice([1e-3, 1.0, 30.0]))
+        b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        D2 = (2 * (md // 2) + 1) ** 2
+        go = rng.standard_normal((B, D2, H, W)).astype(np.float32)
+        ref = orc.corr_fwd(a, b, md, 1, md, 1, 2)
+        out = torch.full((B, D2, H, W), float("nan"), device=dev)
+        fn2_capi.correlation_forward(D(a), D(b), md, 1, md, 1, 2, out=out)
+        s = max(1.0, float(np.abs(ref).max()))
+        e = mx(out.cpu().numpy(), ref) / s; note("corr_fwd", e); assert e <= 3e-6, ("fwd", B, C, H, W, md, e)
+        r1, r2 = orc.corr_bwd(a, b, go, md, 1, md, 1, 2)
+        g1 = torch.full((B, C, H, W), float("nan"), device=dev); g2 = torch.full_like(g1, float("nan"))
+        fn2_capi.correlation_backward(D(a), D(b), D(go), md, 1, md, 1, 2, out=(g1, g2))
+        s = max(1.0, float(np.abs(r1).max()), float(np.abs(r2).max()))
+        e = max(mx(g1.cpu().numpy(), r1), mx(g2.cpu().numpy(), r2)) / s; note("corr_bwd", e); assert e <= 6e-6, ("bwd", B, C, H, W, md, e)
+        ncorr += 1
+    else:
+        B, C, H, W, bil = int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 130)), int(rng.integers(1, 200)), bool(rng.integers(0, 2))
+        img = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        flow = (rng.standard_normal((B, 2, H, W)) * float(rng.choice([0.5, 3.0, 12.0]))).astype(np.float32)
+        flow.reshape(-1)[rng.integers(0, flow.size, max(1, flow.size // 40))] *= 40.0
+        gout = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        lib, P, st = fn2_capi.lib(), (lambda t: __import__("ctypes").c_void_p(t.data_ptr())), None
+        import ctypes
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        imd, fld, god = D(img), D(flow), D(gout)
+        out = torch.full((B, C, H, W), float("nan"), device=dev)
+        assert lib.fn2_resample2d_forward(P(imd), None, P(fld), P(out), B, C, H, W, H, W, 1, int(bil), st) == 0
+        e = mx(out.cpu().numpy(), orc.resample_fwd(img, flow, 1, bil)); note("resample_fwd", e); assert e <= 1e-4, ("rfwd", B, C, H, W, bil, e)
+        gi, gf = torch.zeros(B, C, H, W, device=dev), torch.full((B, 2, H, W), float("nan"), device=dev)
+        assert lib.fn2_resample2d_backward(P(imd), None, P(fld), P(god), P(gi), P(gf), B, C, H, W, H, W, 1, int(bil), st) == 0
+        rgi, rgf = orc.resample_bwd(img, flow, gout, 1, bil)
+        s = max(1.0, float(np.abs(rgi).max()), float(np.abs(rgf).max()))
+        e = max(mx(gi.cpu().numpy(), rgi), mx(gf.cpu().numpy(), rgf)) / s; note("resample_bwd", e); assert e <= 2e-5, ("rbwd", B, C, H, W, bil, e)
+        pair = rng.standard_normal((B, 2 * C, H, W)).astype(np.float32)
+        got = fn2_capi.warp_diff_norm_cat(D(pair), fld, 20.0, bil).cpu().numpy()
+        warped = orc.resample_fwd(np.ascontiguousarray(pair[:, C:]), flow, 1, bil)
+        refc = np.concatenate((pair, warped, flow * (np.float32(1.0) / np.float32(20.0)), orc.chnorm_fwd(pair[:, :C] - warped)), axis=1)
+        e = mx(got, refc); note("warp_diff_norm_cat", e); assert e <= 1e-4, ("n2", B, C, H, W, bil, e)
+        nimg += 1
+print("soak ok: %d correlation cases, %d image cases in %.0f s; worst normalised errors %s" % (ncorr, nimg, time.time() - t0, {k: float("%.3g" % v) for k, v in worst.items()}))
