@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64 * (16 / NAB), (NST == 1 ? (NAB == 2 ? 4 : 2) : (
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // Task decode.  Dispatching the grid takes ~14 us, so within each batch item the tasks whose neighbour
+    // Task decode.  Late-dispatched workgroups finish last, so within each batch item the tasks whose neighbour
     // rows are all padding (they only write zeros) come LAST: the tasks with real work start earlier.
     const int HL = p.H >> 1;
     unsigned t = xcd_remap(blockIdx.x, gridDim.x);
