@@ -333,7 +333,8 @@ template <int TX> struct BT {
 __device__ __attribute__((aligned(16))) const float kZeroBlock[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no neighbour DMA, 4 no G DMA, 8 no stores, 16 neighbour DMA
-// before the G part, 128 s_memtime stamps of one phase dumped over gradInput1, 256 no s_setprio around the DMA issue
+// before the G part, 128 s_memtime stamps of one phase dumped over gradInput1, 256 no s_setprio around the DMA issue,
+// 1024 neighbour tile in 16 one-row DMAs per wave instead of 8 two-row ones (+10 us: the issue cost is per instruction)
 template <int TX, int NV, int NCT, int VAR = 0>
 __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
 {
@@ -377,8 +378,10 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
     // instruction k of wave w covers rows (k*NW + w)*RPI .. of the (ch = row >> 2, bi = row & 3) list, i.e. always the
     // same bi0 = (w*RPI) & 3 and channels 2k + (w*RPI >> 2); lane = (row in instruction, 16 B piece)
     constexpr int PR = T::RF / 4;                                   // pieces per row
+    constexpr int RPI = (VAR & 1024) ? 1 : T::RPI;                  // VAR 1024 (profiling): one row per instruction
+    constexpr int NI = 64 / (NW * RPI), CSTEP = (NW * RPI) / 4 > 0 ? (NW * RPI) / 4 : 1;   // instructions per wave, channel step
     const int s_r = lane / PR, s_pc = lane - s_r * PR;
-    const int s_bi = ((wave * T::RPI) & 3) + s_r, s_ch0 = (wave * T::RPI) >> 2;
+    const int s_bi = ((wave * RPI) & 3) + s_r, s_ch0 = (wave * RPI) >> 2;
     const int s_x = X0 - 2 * p.dr + 4 * s_pc;
     const bool s_col_ok = (s_x >= 0) && (s_x < p.W);
     auto nbr_dma = [&](int u, int ct, int buf) __attribute__((always_inline)) {
@@ -388,12 +391,12 @@ __global__ __launch_bounds__(8 * TX, 2) void corr_bwd_mfma_bf16x3(Args p)
         const int il = 4 * rg - p.dr + 4 * u + s_bi;
         const bool ok = s_col_ok && (il >= 0) && (il < HL);
         const float *src = ok ? nbr_n + (long)(ct * CK + s_ch0) * HW_ + (2 * il + py) * p.W + s_x : zeros;
-        const long step = ok ? 2 * (long)HW_ : 0;
-        float *dst = Ns + buf * NB_FLOATS + s_ch0 * S_CH + ((wave * T::RPI) & 3) * S_ROW;
-        if (lane < T::RPI * PR) {
+        const long step = ok ? CSTEP * (long)HW_ : 0;
+        float *dst = Ns + buf * NB_FLOATS + s_ch0 * S_CH + ((wave * RPI) & 3) * S_ROW;
+        if (lane < RPI * PR) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                __builtin_amdgcn_global_load_lds(src + k * step, (lds_ptr)(dst + k * 2 * S_CH), 16, 0, 0);
+            for (int k = 0; k < NI; ++k)
+                __builtin_amdgcn_global_load_lds(src + k * step, (lds_ptr)(dst + k * CSTEP * S_CH), 16, 0, 0);
         }
     };
 
@@ -676,7 +679,7 @@ int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout
     const bool bf_ok = bwd_bf16x3_ok(in1, in2, gout, C, W, a.dr);
     if (tune == 0) tune = bf_ok ? 4 : 6;
 
-    if (tune == 4 || tune == 5 || (tune >= 40 && tune < 400)) {
+    if (tune == 4 || tune == 5 || (tune >= 40 && tune < 1200)) {
         if (!bf_ok) return FN2_EUNSUPPORTED;
         const int TX = (tune == 5) ? 64 : 32;
         a.NXT = (W + TX - 1) / TX;
@@ -687,7 +690,7 @@ int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout
         if (tune == 5) { hipLaunchKernelGGL((mb::corr_bwd_mfma_bf16x3<64, 6, 4, 0>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status(); }
         switch (tune == 4 ? 0 : tune - 40) {
 #define FN2_BV(V) case V: hipLaunchKernelGGL((mb::corr_bwd_mfma_bf16x3<32, 6, 4, V>), dim3((unsigned)ntasks), dim3(256), 0, s, a); return launch_status();
-            FN2_BV(0) FN2_BV(1) FN2_BV(6) FN2_BV(7) FN2_BV(16) FN2_BV(128) FN2_BV(256)
+            FN2_BV(0) FN2_BV(1) FN2_BV(6) FN2_BV(7) FN2_BV(16) FN2_BV(128) FN2_BV(256) FN2_BV(1024)
 #undef FN2_BV
         default: return FN2_EUNSUPPORTED;
         }
