@@ -18,6 +18,7 @@ EXPORTS = [
     "fn2_correlation_backward", "fn2_correlation_backward_ex",
     "fn2_resample2d_forward", "fn2_resample2d_backward", "fn2_warp_diff_norm_cat",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
+    "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe",
 ]
 
 _lib = None
@@ -37,6 +38,7 @@ def lib():
         _lib.fn2_strerror.argtypes = [ctypes.c_int]
         for name in EXPORTS[1:]:
             getattr(_lib, name).restype = ctypes.c_int
+        _lib.fn2_multiscale_workspace_bytes.restype = ctypes.c_size_t
     return _lib
 
 
@@ -115,3 +117,28 @@ def warp_diff_norm_cat(pair, flow, div_flow=20.0, bilinear=True):
         check(lib().fn2_warp_diff_norm_cat(_p(pair), _p(flow), _p(out), ctypes.c_float(div_flow), B, C, H, W,
                                            1 if bilinear else 0, _stream(pair)), "fn2_warp_diff_norm_cat")
     return out
+
+
+def multiscale_l1_epe(outputs, target, weights, start_scale=4, div_flow=0.05, want_grads=False, grad_scale=1.0):
+    """SURVEY.md 8f N3 (losses.py:52-86, L1 norm): returns (sums, grads).  sums is a device tensor of 2*n floats --
+    sums[i] = sum |out_i - AvgPool_{k_i}(div_flow * target)|, sums[n+i] = sum of the per-pixel channel 2-norms; grads
+    (if requested) are grad_scale * weights[i] / numel(out_i) * sign(out_i - t_i)."""
+    import torch
+    n = len(outputs)
+    B, two, H, W = target.shape
+    assert two == 2 and target.is_contiguous() and target.dtype == torch.float32
+    for i, o in enumerate(outputs):
+        k = start_scale << i
+        assert o.is_contiguous() and o.dtype == torch.float32 and tuple(o.shape) == (B, 2, H // k, W // k), (i, o.shape)
+    sums = torch.empty(2 * n, dtype=torch.float32, device=target.device)
+    grads = [torch.empty_like(o) for o in outputs] if want_grads else None
+    wsb = lib().fn2_multiscale_workspace_bytes(B, H, W, start_scale, n)
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=target.device)
+    outs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outputs])
+    gptr = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]) if want_grads else None
+    wts = (ctypes.c_float * n)(*[float(w) for w in weights])
+    with torch.cuda.device_of(target):
+        check(lib().fn2_multiscale_l1_epe(outs, _p(target), _p(sums), gptr, wts, ctypes.c_float(grad_scale), B, H, W,
+                                          start_scale, n, ctypes.c_float(div_flow), _p(ws), ctypes.c_size_t(wsb),
+                                          _stream(target)), "fn2_multiscale_l1_epe")
+    return sums, grads

@@ -1,0 +1,51 @@
+"""FlowNet2's MultiScale training loss (reference losses.py:52-86, norm='L1') and its EPE metric as one
+fused pass (fn2_multiscale_l1_epe) instead of five AvgPool2d passes over the target and ~35 small launches.
+
+    criterion = MultiScaleL1()                      # startScale=4, numScales=5, l_weight=0.32, like the reference
+    loss, epe = criterion(outputs, target)          # outputs: the tuple of 5 predictions FlowNetC returns in training
+    loss.backward()                                 # d loss / d outputs[i]; the target gets no gradient
+
+The single-tensor branch of the reference (eval: plain L1 + EPE on full resolution) is ordinary PyTorch and not
+reproduced here."""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+import fn2_capi
+
+
+class MultiScaleL1Function(Function):
+    @staticmethod
+    def forward(ctx, target, start_scale, div_flow, weights, coef, *outputs):
+        outputs = [o.contiguous() for o in outputs]
+        need = any(o.requires_grad for o in outputs)
+        sums, grads = fn2_capi.multiscale_l1_epe(outputs, target.contiguous(), weights, start_scale, div_flow, want_grads=need)
+        both = (sums * coef).view(2, -1).sum(dim=1)     # [sum_i w_i mean|out_i - t_i| (losses.py:78), sum_i w_i mean||.||_2 (:77)]
+        loss, epe = both[0], both[1]
+        ctx.grads = grads
+        ctx.mark_non_differentiable(epe)
+        return loss, epe
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_epe):
+        return (None, None, None, None, None) + tuple(g.mul_(grad_loss) for g in ctx.grads)
+
+
+class MultiScaleL1(nn.Module):
+    def __init__(self, startScale=4, numScales=5, l_weight=0.32, div_flow=0.05):
+        super().__init__()
+        self.startScale, self.numScales, self.div_flow = startScale, numScales, div_flow
+        self.loss_weights = [l_weight / 2 ** s for s in range(numScales)]
+        self.loss_labels = ["MultiScale-L1", "EPE"]
+        self._coef = {}     # (device, shapes) -> w_i / N_i for the L1 sums followed by w_i / (N_i / 2) for the EPE sums
+
+    def forward(self, output, target):
+        assert isinstance(output, (tuple, list)) and len(output) == self.numScales
+        key = (target.device, tuple(o.numel() for o in output))
+        coef = self._coef.get(key)
+        if coef is None:
+            n = [max(o.numel(), 1) for o in output]
+            vals = [w / k for w, k in zip(self.loss_weights, n)] + [w / (k / 2) for w, k in zip(self.loss_weights, n)]
+            coef = self._coef[key] = torch.tensor(vals, dtype=torch.float32, device=target.device)
+        loss, epe = MultiScaleL1Function.apply(target, self.startScale, self.div_flow, tuple(self.loss_weights), coef, *output)
+        return [loss, epe]

@@ -146,6 +146,25 @@ int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const 
 int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, float div_flow,
                            int B, int C, int H, int W, int bilinear, void *stream);
 
+/* "Next" row N3: the training loss of FlowNet2 -- MultiScale with the L1 norm (losses.py:52-86) -- and
+ * the EPE metric (losses.py:11-12) in one pass over the target flow instead of five AvgPool2d passes and ~35 launches.
+ *   outputs[i] : B x 2 x (H/k_i) x (W/k_i) contiguous device tensors, k_i = start_scale << i, i < num_scales (host array
+ *                of device pointers); start_scale a power of two <= 16, num_scales <= 5 with k_max / start_scale <= 16
+ *   target     : B x 2 x H x W contiguous
+ *   sums       : 2*num_scales floats on the device, fully written:
+ *                sums[i]              = sum |out_i - AvgPool_ki(div_flow * target)|        (L1_i  = sums[i] / (B*2*H_i*W_i))
+ *                sums[num_scales + i] = sum over pixels of the channel 2-norm of that     (EPE_i = ... / (B*H_i*W_i))
+ *   grads      : NULL, or num_scales device tensors shaped like outputs[i], fully written with
+ *                grad_scale * weights[i] / (B*2*H_i*W_i) * sign(out_i - t_i) = d(sum_i w_i L1_i)/d out_i * grad_scale
+ *   weights    : host array of num_scales loss weights (only used for grads)
+ *   workspace  : device scratch of fn2_multiscale_workspace_bytes(...) bytes (per-workgroup partial sums; the result is
+ *                deterministic)
+ * float32. */
+size_t fn2_multiscale_workspace_bytes(int B, int H, int W, int start_scale, int num_scales);
+int fn2_multiscale_l1_epe(const float *const *outputs, const float *target, float *sums, float *const *grads,
+                          const float *weights, float grad_scale, int B, int H, int W, int start_scale, int num_scales,
+                          float div_flow, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Replaces channelnorm_kernel_forward (channelnorm_kernel.cuh:5-8; kernel
  * channelnorm_kernel.cu:18-60).  in : B x C x H x W contiguous, out : B x 1 x H x W contiguous.
  * norm_deg is accepted and ignored by the reference kernels (always L2); not part of this ABI. */

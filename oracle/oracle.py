@@ -149,3 +149,20 @@ class Oracle:
             rc = f(pa, po, pg, ctypes.c_long(H * W), gin.ctypes.data_as(_P), _I(B), _I(C), _I(H), _I(W))
         assert rc == 0, rc
         return gin
+
+
+def multiscale_l1_epe_sums(outputs, target, start_scale=4, div_flow=0.05):
+    """numpy restatement of the per-scale sums of the reference's MultiScale loss (losses.py:74-78) and EPE (:12):
+    t = div_flow * target (:74); t_i = AvgPool2d(k_i, k_i)(t) with k_i = start_scale << i (:69,:76), floor semantics;
+    returns ([sum |out_i - t_i|], [sum_{b,y,x} ||t_i - out_i||_2]) in float64 from float32 inputs (test infrastructure)."""
+    t = (np.float32(div_flow) * target.astype(np.float32)).astype(np.float32)
+    l1, epe = [], []
+    for i, o in enumerate(outputs):
+        k = start_scale << i
+        B, _, H, W = t.shape
+        Hi, Wi = H // k, W // k
+        ti = t[:, :, :Hi * k, :Wi * k].reshape(B, 2, Hi, k, Wi, k).astype(np.float64).mean(axis=(3, 5))
+        d = o.astype(np.float64) - ti
+        l1.append(np.abs(d).sum())
+        epe.append(np.sqrt((d * d).sum(axis=1)).sum())
+    return np.array(l1), np.array(epe)

@@ -51,4 +51,34 @@ with torch.no_grad():
     assert torch.equal(wd(x, flow), unfused())
     res["N2_algorithmic_bytes"] = (6 + 2 + 12) * 8 * 384 * 512 * 4
     res["N2_fused_GBps"] = round(res["N2_algorithmic_bytes"] / (res["N2_fused_us"] * 1e-6) / 1e9, 1)
+# N3: losses.py:52-86 (MultiScale, L1) + EPE at bs 8 @ 384x512, forward + backward to the five predictions
+from losses_fused import MultiScaleL1
+target = (torch.randn(8, 2, 384, 512, generator=g) * 5.0).to(dev)
+outs = [(torch.randn(8, 2, 384 // (4 << i), 512 // (4 << i), generator=g) * 0.3).to(dev).requires_grad_(True) for i in range(5)]
+weights = [0.32 / 2 ** i for i in range(5)]
+pools = [torch.nn.AvgPool2d(4 << i, 4 << i) for i in range(5)]
+
+
+def ref_loss():
+    t = 0.05 * target
+    loss, epe = 0, 0
+    for i, o in enumerate(outs):
+        ti = pools[i](t)
+        epe = epe + weights[i] * torch.norm(ti - o, p=2, dim=1).mean()
+        loss = loss + weights[i] * torch.abs(o - ti).mean()
+    loss.backward()
+    return loss, epe
+
+
+crit = MultiScaleL1()
+
+
+def fused_loss():
+    loss, epe = crit(tuple(outs), target)
+    loss.backward()
+    return loss, epe
+
+
+res["N3_unfused_us"] = timeit(ref_loss)
+res["N3_fused_us"] = timeit(fused_loss)
 print(json.dumps(res))

@@ -643,3 +643,43 @@ def test_resample_channelnorm_fuzz_vs_oracle(dev, oracle, case):
     warped = oracle.resample_fwd(np.ascontiguousarray(pair[:, C:]), flow, 1, bilinear)
     refc = np.concatenate((pair, warped, flow * (np.float32(1.0) / np.float32(20.0)), oracle.chnorm_fwd(pair[:, :C] - warped)), axis=1)
     assert max_abs(got, refc) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (8, 384, 512), (1, 100, 200), (3, 192, 64)])
+def test_multiscale_l1_epe(dev, shape):
+    """the fused MultiScale-L1 loss + EPE against the numpy restatement of losses.py:52-86, against the
+    reference's formulation in plain PyTorch on the GPU, and its gradient against autograd of that formulation."""
+    import fn2_capi
+    from oracle.oracle import multiscale_l1_epe_sums
+    from losses_fused import MultiScaleL1
+    B, H, W = shape
+    rng = np.random.default_rng(B + H + W)
+    target = (rng.standard_normal((B, 2, H, W)) * 5.0).astype(np.float32)
+    outs = [rng.standard_normal((B, 2, H // (4 << i), W // (4 << i))).astype(np.float32) * 0.3 for i in range(5)]
+    weights = [0.32 / 2 ** i for i in range(5)]
+    td, od = to_dev(target, dev), [to_dev(o, dev) for o in outs]
+    sums, _ = fn2_capi.multiscale_l1_epe(od, td, weights)
+    rl1, repe = multiscale_l1_epe_sums(outs, target)
+    got = sums.cpu().numpy().astype(np.float64)
+    for i in range(5):
+        if outs[i].size == 0:
+            assert got[i] == 0 and got[5 + i] == 0
+            continue
+        assert abs(got[i] - rl1[i]) <= 2e-5 * max(1.0, rl1[i]), (i, got[i], rl1[i])
+        assert abs(got[5 + i] - repe[i]) <= 2e-5 * max(1.0, repe[i]), (i, got[5 + i], repe[i])
+    # the reference's statements (losses.py:74-78) on the same device tensors, and autograd through them
+    if all(o.size for o in outs):
+        ot = [o.clone().requires_grad_(True) for o in od]
+        t = 0.05 * td
+        loss_ref = sum(w * torch.abs(o - torch.nn.functional.avg_pool2d(t, 4 << i, 4 << i)).mean() for i, (w, o) in enumerate(zip(weights, ot)))
+        epe_ref = sum(w * torch.norm(torch.nn.functional.avg_pool2d(t, 4 << i, 4 << i) - o, p=2, dim=1).mean() for i, (w, o) in enumerate(zip(weights, ot)))
+        loss_ref.backward()
+        of = [o.clone().requires_grad_(True) for o in od]
+        loss, epe = MultiScaleL1()(tuple(of), td)
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-5 * max(1.0, abs(float(loss_ref.detach())))
+        assert abs(float(epe.detach()) - float(epe_ref.detach())) <= 1e-5 * max(1.0, abs(float(epe_ref.detach())))
+        (2.0 * loss).backward()
+        for a, b in zip(of, ot):
+            # sign() flips where |out - t_i| is at rounding level: allow a handful of such elements
+            diff = (a.grad - 2.0 * b.grad).abs()
+            assert int((diff > 1e-9).sum()) <= max(2, a.numel() // 5000), int((diff > 1e-9).sum())
