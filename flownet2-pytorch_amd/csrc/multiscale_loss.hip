@@ -23,7 +23,7 @@ struct MsArgs {
     float gw[MS_MAX_SCALES];       // grad_scale * w_i / N_i
     const float *target;
     float *partial;                // [nblocks][2 * ns]
-    int B, H, W, s0, ns, kmax, bx, by;
+    int B, H, W, s0, ns, kmax, bx, by, vec4;
     float div_flow;
 };
 
@@ -53,8 +53,16 @@ __global__ __launch_bounds__(256) void multiscale_l1_epe_kernel(MsArgs p)
             float sum = 0.0f;
             if (y0 + k <= p.H && x0 + k <= p.W) {
                 const float *T = p.target + ((long)b * 2 + c) * HW;
-                for (int yy = 0; yy < k; ++yy)
-                    for (int xx = 0; xx < k; ++xx) sum = sum + p.div_flow * T[(long)(y0 + yy) * p.W + x0 + xx];
+                if (k == 4 && p.vec4) {          // one 16 B load per cell row (same summation order)
+                    for (int yy = 0; yy < 4; ++yy) {
+                        const float4 v = *reinterpret_cast<const float4 *>(T + (long)(y0 + yy) * p.W + x0);
+                        sum = sum + p.div_flow * v.x; sum = sum + p.div_flow * v.y;
+                        sum = sum + p.div_flow * v.z; sum = sum + p.div_flow * v.w;
+                    }
+                } else {
+                    for (int yy = 0; yy < k; ++yy)
+                        for (int xx = 0; xx < k; ++xx) sum = sum + p.div_flow * T[(long)(y0 + yy) * p.W + x0 + xx];
+                }
             }
             lv[0][c][tid] = sum;
         }
@@ -155,6 +163,7 @@ extern "C" int fn2_multiscale_l1_epe(const float *const *outputs, const float *t
     hipStream_t s = static_cast<hipStream_t>(stream);
     a.target = target; a.partial = static_cast<float *>(workspace);
     a.B = B; a.H = H; a.W = W; a.s0 = start_scale; a.ns = num_scales; a.div_flow = div_flow;
+    a.vec4 = (W % 4 == 0) && aligned(target, 16);
     for (int i = 0; i < MS_MAX_SCALES; ++i) { a.out[i] = nullptr; a.grad[i] = nullptr; a.gw[i] = 0.0f; }
     for (int i = 0; i < num_scales; ++i) {
         if (!outputs[i]) return FN2_EINVAL;
