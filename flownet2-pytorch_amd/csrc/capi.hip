@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "corr_params.h"
+#include "fn2_debug.h"
 
 
 extern "C" const char *fn2_strerror(int code)
@@ -40,10 +41,10 @@ extern "C" int fn2_correlation_output_shape(int H, int W, int pad_size, int kern
     return FN2_OK;
 }
 
-extern "C" int fn2_correlation_forward_fused(const void *in1, const void *in2, void *out, int64_t out_batch_stride,
-                                             float negative_slope, int dtype, int B, int C, int H, int W,
-                                             int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
-                                             int algo, void *stream)
+static int corr_forward_impl(const void *in1, const void *in2, void *out, int64_t out_batch_stride,
+                             float negative_slope, int dtype, int B, int C, int H, int W,
+                             int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                             int algo, bool debug_variant, void *stream)
 {
     using namespace fn2;
     const size_t es = dtype_size(dtype);
@@ -58,20 +59,43 @@ extern "C" int fn2_correlation_forward_fused(const void *in1, const void *in2, v
     if (!in1 || !in2 || !out) return FN2_EINVAL;
     if (!aligned(in1, es) || !aligned(in2, es) || !aligned(out, es)) return FN2_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // profiling instantiations (wrong or partial outputs by design) are only reachable through fn2_debug_* (fn2_debug.h)
+    if (!debug_variant && (algo < FN2_CORR_AUTO || algo > FN2_CORR_MFMA_F16X2)) return FN2_EINVAL;
+    // f16x2: two-term f16 split done once per staged value, 3 MFMAs per block product (correlation_f16x2.hip)
+    const bool f16x2_ok = corr_f16x2_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2) &&
+                          aligned(in1, 16) && aligned(in2, 16) && aligned(out, 16) && (out_batch_stride % 4 == 0);
+    if (debug_variant && algo >= 5000) {
+        if (!f16x2_ok) return FN2_EUNSUPPORTED;
+        return corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
+                                  p.out_bs, p.slope, B, C, H, W, algo - 5000, s);
+    }
+    if (algo == FN2_CORR_MFMA_F16X2 && !f16x2_ok) return FN2_EUNSUPPORTED;
+    if (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok))
+        return corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
+                                  p.out_bs, p.slope, B, C, H, W, 0, s);
     const bool mfma_ok = corr_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                   stride2) && aligned(in1, 8) && aligned(in2, 8) && aligned(out, 8) &&
                          (out_batch_stride % 2 == 0);
-    const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || algo >= 100);
+    const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || debug_variant);
     if (wants_mfma && !mfma_ok) return FN2_EUNSUPPORTED;
     if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok)) {
         rc = corr_forward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
                                    static_cast<float *>(out), p.out_bs, p.slope, B, C, H, W, max_displacement,
-                                   algo, s); // 0 auto, 2 fp32 MFMA, 3 bf16x3, >= 100 profiling instantiations
+                                   algo, s); // 0 auto, 2 fp32 MFMA, 3 bf16x3, >= 100 profiling instantiations (debug only)
         // automatic selection: a shape the tiled kernels decline (nothing launched) goes to the general kernel
         if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
     }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_forward_direct(in1, in2, out, dtype, p, s);
+}
+
+extern "C" int fn2_correlation_forward_fused(const void *in1, const void *in2, void *out, int64_t out_batch_stride,
+                                             float negative_slope, int dtype, int B, int C, int H, int W,
+                                             int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                             int algo, void *stream)
+{
+    return corr_forward_impl(in1, in2, out, out_batch_stride, negative_slope, dtype, B, C, H, W, pad_size, kernel_size,
+                             max_displacement, stride1, stride2, algo, false, stream);
 }
 
 extern "C" int fn2_correlation_forward_ex(const void *in1, const void *in2, void *out, int dtype,
@@ -96,11 +120,11 @@ extern "C" int fn2_correlation_forward(const void *in1, const void *in2, void *o
                                       stride1, stride2, FN2_CORR_AUTO, stream);
 }
 
-extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *grad_out,
-                                           void *grad_in1, void *grad_in2, int dtype,
-                                           int B, int C, int H, int W,
-                                           int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
-                                           int algo, void *stream)
+static int corr_backward_impl(const void *in1, const void *in2, const void *grad_out,
+                              void *grad_in1, void *grad_in2, int dtype,
+                              int B, int C, int H, int W,
+                              int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                              int algo, bool debug_variant, void *stream)
 {
     using namespace fn2;
     const size_t es = dtype_size(dtype);
@@ -116,15 +140,17 @@ extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, con
         !aligned(grad_in2, es))
         return FN2_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!debug_variant && (algo < FN2_CORR_AUTO || algo > FN2_CORR_MFMA_F16X2)) return FN2_EINVAL;
+    if (!debug_variant && algo == FN2_CORR_MFMA_F16X2) return FN2_EUNSUPPORTED;   // forward only
     const bool mfma_ok = corr_bwd_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                       stride2) &&
                          aligned(in1, 8) && aligned(in2, 8) && aligned(grad_out, 8);
-    const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || algo >= 100);
+    const bool wants_mfma = (algo == FN2_CORR_MFMA_F32 || algo == FN2_CORR_MFMA_BF16X3 || debug_variant);
     if (wants_mfma && !mfma_ok) return FN2_EUNSUPPORTED;
     if (wants_mfma || (algo == FN2_CORR_AUTO && mfma_ok)) {
         // internal tune: 0 = automatic (bf16x3 where its extra preconditions hold), 6 = fp32 MFMA, 4 = bf16x3 or
         // FN2_EUNSUPPORTED, algo - 100 = profiling variants
-        const int tune = algo == FN2_CORR_MFMA_F32 ? 6 : algo == FN2_CORR_MFMA_BF16X3 ? 4 : algo >= 100 ? algo - 100 : 0;
+        const int tune = algo == FN2_CORR_MFMA_F32 ? 6 : algo == FN2_CORR_MFMA_BF16X3 ? 4 : debug_variant ? algo - 100 : 0;
         rc = corr_backward_mfma_f32(static_cast<const float *>(in1), static_cast<const float *>(in2),
                                     static_cast<const float *>(grad_out), static_cast<float *>(grad_in1),
                                     static_cast<float *>(grad_in2), B, C, H, W, max_displacement, tune, s);
@@ -132,6 +158,16 @@ extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, con
     }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
     return corr_backward_direct(in1, in2, grad_out, grad_in1, grad_in2, dtype, p, s);
+}
+
+extern "C" int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *grad_out,
+                                           void *grad_in1, void *grad_in2, int dtype,
+                                           int B, int C, int H, int W,
+                                           int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                           int algo, void *stream)
+{
+    return corr_backward_impl(in1, in2, grad_out, grad_in1, grad_in2, dtype, B, C, H, W, pad_size, kernel_size,
+                              max_displacement, stride1, stride2, algo, false, stream);
 }
 
 extern "C" int fn2_correlation_backward(const void *in1, const void *in2, const void *grad_out,
@@ -142,4 +178,27 @@ extern "C" int fn2_correlation_backward(const void *in1, const void *in2, const 
 {
     return fn2_correlation_backward_ex(in1, in2, grad_out, grad_in1, grad_in2, dtype, B, C, H, W, pad_size,
                                        kernel_size, max_displacement, stride1, stride2, FN2_CORR_AUTO, stream);
+}
+
+// ---- profiling / ablation instantiations (fn2_debug.h): not part of the public ABI, outputs may be wrong by design
+extern "C" int fn2_debug_correlation_forward(const void *in1, const void *in2, void *out, int dtype, int B, int C, int H, int W,
+                                             int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                             int variant, void *stream)
+{
+    if (variant < 100) return FN2_EINVAL;
+    int nOut = 0, oH = 0, oW = 0;
+    const int rc = fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut, &oH, &oW);
+    if (rc != FN2_OK) return rc;
+    return corr_forward_impl(in1, in2, out, (int64_t)nOut * oH * oW, 1.0f, dtype, B, C, H, W, pad_size, kernel_size,
+                             max_displacement, stride1, stride2, variant, true, stream);
+}
+
+extern "C" int fn2_debug_correlation_backward(const void *in1, const void *in2, const void *grad_out, void *grad_in1,
+                                              void *grad_in2, int dtype, int B, int C, int H, int W, int pad_size,
+                                              int kernel_size, int max_displacement, int stride1, int stride2, int variant,
+                                              void *stream)
+{
+    if (variant < 100) return FN2_EINVAL;
+    return corr_backward_impl(in1, in2, grad_out, grad_in1, grad_in2, dtype, B, C, H, W, pad_size, kernel_size,
+                              max_displacement, stride1, stride2, variant, true, stream);
 }

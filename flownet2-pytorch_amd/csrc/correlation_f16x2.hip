@@ -1,0 +1,430 @@
+// correlation_f16x2.hip -- FlowNetC cost volume (correlation forward) on the gfx950 f16 matrix cores with a
+// two-term split of the fp32 operands that is done ONCE per staged value.
+//
+// Replaces reference kernels channels_first + correlation_forward (correlation_cuda_kernel.cu:46-70, :73-147) for
+// FlowNetC's configuration (FlowNetC.py:28,31: kernel_size 1, stride1 1, stride2 2, pad_size == max_displacement == 20,
+// fp32) on maps up to 64 pixels wide:
+//     out[n, tj*21 + ti, y, x] = (1/C) * sum_c in1[n,c,y,x] * in2[n,c, y + 2(tj-10), x + 2(ti-10)]      (in2 = 0 outside)
+//
+// Numerics.  Every fp32 operand x is written as x = h + l with h = RNE_f16(x) and l = RNE_f16(x - h) (x - h is exact in
+// fp32), and a product is formed as  ah*bh + ah*bl + al*bh  on v_mfma_f32_16x16x32_f16 with fp32 accumulation.  The
+// representation error of an operand is max(2^-22 |x|, 2^-25), the dropped term al*bl is below 2^-22 |ab|: fp32-class
+// results (measured against fp64 in tests/test_gpu_parity.py) from 3 matrix instructions per 16x16x32 block product
+// instead of the 6 of the bf16x3 kernel, and none of its per-fragment split work.  |x| >= 65520 does not fit an f16: h
+// becomes inf, every output that involves the value comes out non-finite, and the store loop recomputes exactly those
+// outputs with a plain fp32 fma chain (exact_corr below) -- correct for any finite fp32 input, fast for |x| < 65520.
+//
+// Mapping.  stride2 = 2 keeps pixel parity, so each of the 4 parity classes is a dense lattice (I, J) = (y>>1, x>>1) on
+// which the displacement window is the contiguous 21x21 box.  A 4x4 block of lattice pixels of in1 ("A block") against
+// a 4x4 block of in2 ("B block") over 32 channels is one MFMA chain; both block grids are ALIGNED to 4 lattice columns
+// (blocks are then whole 8-byte chunks of the LDS image, which is what the transposing LDS read needs), rows of B blocks
+// start at 4*rg - 10 + 4*u.  An A column block a meets the B column blocks a-3 .. a+3 that exist (44 block pairs per
+// parity and row-block pair instead of 48 on a grid offset by the radius).
+//
+// Work decomposition.  One workgroup (8 waves, one per CU) = one task (n, y parity, 4 lattice rows rg, B row block u):
+// A tile and B tile of 4 lattice rows x 64 pixels.  Wave w takes x parity w&1 and the two A column blocks of role w>>1:
+// {0,3}, {1,2}, {4,7}, {5,6} -- 11 block pairs each, 6 or 7 B fragments.
+//
+// Per step of 32 channels (one barrier per step, LDS double-buffered, two register sets for the loads):
+//   - the loads of step s+2 are issued (8 x 16 B per lane; buffer loads: rows outside the image come back as zeros from the
+//     range check, no select);
+//   - the values of step s+1, loaded during step s-1, are split (cvt_pk / fma_mix / cvt_pk: 2 VALU per value) and written as
+//     8-byte chunks [4 lattice columns of one parity] of the image [tile][term][parity][channel][column block][row] of
+//     the other LDS buffer -- interleaved with
+//   - the MFMAs of step s: every wave reads its operands with ds_read_b64_tr_b16 (the LDS transpose read: 4 channel rows
+//     x 16 pixels -> per lane 4 channels of one pixel), two reads per operand, one address register and immediates for
+//     all 36 reads; 33 MFMAs.
+// Epilogue: accumulators -> LDS [plane (ai,bi)][ti][x] (64 floats per row, 16-byte slots rotated by 4 bi + ai: <= 2-way write
+// conflicts, which a ds_write_b32 does not pay for) -> rows leave as 16 B per lane, 4 rows per instruction.
+#include <type_traits>
+
+#include "corr_params.h"
+
+namespace fn2 {
+namespace hf {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#define FN2_LDS(T) __attribute__((address_space(3))) T
+
+constexpr int DR = 10, D = 2 * DR + 1, NU = 6;   // displacement radius (lattice), planes per axis, B row blocks per A row block
+constexpr int CK = 32;                            // channels per step
+constexpr int CHS = 288;                          // bytes per channel of one (tile, term, parity) plane: 8 column blocks x 4 rows x 8 B + 32
+constexpr int PARS = CK * CHS;                    // 9216
+constexpr int TERM = 2 * PARS;                    // 18432
+constexpr int TILE = 2 * TERM;                    // 36864
+constexpr int BUF = 2 * TILE;                     // 73728: A tile + B tile of one step
+constexpr int LDS_BYTES = 2 * BUF;                // 147456: two steps
+constexpr int O_RS = 64;                          // epilogue row stride (floats)
+constexpr int O_DUMMY = 16 * D * O_RS;            // sink row for out-of-band entries
+static_assert((O_DUMMY + 64) * 4 <= LDS_BYTES, "epilogue image must fit the operand buffers");
+
+struct Args {
+    const float *in1, *in2;
+    float *out;
+    long out_bs;     // elements between batch items of `out`
+    float slope;     // fused LeakyReLU slope (1 = none)
+    int C, H, W;     // H even, W % 8 == 0, W <= 64
+    int NRG;         // row groups per parity
+};
+
+// wave roles: A column blocks of role r, and the B column blocks they meet
+constexpr int NAB = 2;                            // A blocks per wave
+__host__ __device__ constexpr int a_blk(int role, int ab) { return role == 0 ? (ab ? 3 : 0) : role == 1 ? (ab ? 2 : 1) : role == 2 ? (ab ? 7 : 4) : (ab ? 6 : 5); }
+__host__ __device__ constexpr int m_lo(int role) { return role == 0 ? 0 : role == 1 ? 0 : role == 2 ? 1 : 2; }
+__host__ __device__ constexpr int m_hi(int role) { return role == 0 ? 6 : role == 1 ? 5 : 7; }
+__host__ __device__ constexpr bool meets(int a, int m) { return m >= 0 && m <= 7 && m - a <= 3 && a - m <= 3; }
+__host__ __device__ constexpr int pair_idx(int role, int ab, int m)
+{
+    int idx = 0;
+    for (int mm = m_lo(role); mm <= m_hi(role); ++mm)
+        for (int b = 0; b < NAB; ++b) {
+            if (mm == m && b == ab) return meets(a_blk(role, ab), m) ? idx : -1;
+            if (meets(a_blk(role, b), mm)) ++idx;
+        }
+    return -1;
+}
+constexpr int NP = 11;
+static_assert(pair_idx(0, 1, 6) == NP - 1 && pair_idx(1, 1, 5) == NP - 1 && pair_idx(2, 1, 7) == NP - 1 && pair_idx(3, 1, 7) == NP - 1 &&
+              pair_idx(0, 0, 4) == -1, "11 pairs per role");
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+// x - (float)half: one instruction, exact
+__device__ __forceinline__ float resid_lo(unsigned hp, float x)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(unsigned hp, float x)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_f16(float a, float b)   // v_cvt_pk_f16_f32, round to nearest even
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a, b}, h2));
+}
+
+// One output element as a plain fp32 fma chain over the channels (any finite input): used for outputs whose matrix-core
+// result is non-finite, i.e. an operand did not fit an f16 (or really is inf/nan).
+__device__ __forceinline__ float exact_corr(const Args &p, int n, int y, int x, int tj, int ti)
+{
+    const long HW = (long)p.H * p.W;
+    const int y2 = y + 2 * (tj - DR), x2 = x + 2 * (ti - DR);
+    const float *a = p.in1 + (long)n * p.C * HW + (long)y * p.W + x;
+    const bool inside = y2 >= 0 && y2 < p.H && x2 >= 0 && x2 < p.W;
+    const float *b = p.in2 + (long)n * p.C * HW + (inside ? (long)y2 * p.W + x2 : 0);
+    float s = 0.0f;
+    for (int c = 0; c < p.C; ++c) s = fmaf(a[c * HW], inside ? b[c * HW] : 0.0f, s);
+    return s;
+}
+
+struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
+
+// VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no global stores, 8 no operand reads,
+//      16 no split / LDS staging writes
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- task decode.  Within each batch item the tasks whose B rows are all padding (they only write zeros) come last.
+    const int HL = p.H >> 1;
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_item = 2 * p.NRG * NU;
+    const int n = (int)(t / per_item);
+    int idx = (int)(t % per_item), u = 0, rg = 0, py = 0;
+    {
+        auto ulo = [&](int g) { const int v = DR - 3 - 4 * g; return v <= 0 ? 0 : (v + 3) / 4; };
+        auto uhi = [&](int g) { const int v = (HL - 1 + DR - 4 * g) / 4; return v < NU - 1 ? v : NU - 1; };
+        int R = 0;
+        for (int g = 0; g < p.NRG; ++g) { const int c = uhi(g) - ulo(g) + 1; R += c > 0 ? c : 0; }
+        const bool real = idx < 2 * R;
+        const int per_par = real ? R : p.NRG * NU - R;
+        int r = real ? idx : idx - 2 * R;
+        py = r / per_par; r -= py * per_par;
+        for (int g = 0; g < p.NRG; ++g) {
+            const int lo = ulo(g), hi = uhi(g);
+            const int c = hi - lo + 1 > 0 ? hi - lo + 1 : 0;
+            const int k = real ? c : NU - c;
+            if (r < k) {
+                rg = g;
+                u = real ? lo + r : (c == 0 ? r : (r < lo ? r : hi + 1 + (r - lo)));
+                break;
+            }
+            r -= k;
+        }
+    }
+    py = __builtin_amdgcn_readfirstlane(py); rg = __builtin_amdgcn_readfirstlane(rg); u = __builtin_amdgcn_readfirstlane(u);
+
+    const int ib0 = 4 * rg - DR + 4 * u;                       // first B lattice row
+    const bool all_pad = (ib0 + 3 < 0) || (ib0 >= HL);
+    const long HW = (long)p.H * p.W;
+    const float *in1n = p.in1 + (long)n * p.C * HW;
+    const float *in2n = p.in2 + (long)n * p.C * HW;
+
+    // ---- staging roles.  A step has 32 channels x 4 rows x 8 pieces (8 pixels = 4 lattice columns of each parity) per tile;
+    // slot k (0, 1) of a tile covers channels 16k .. 16k+15: wave w channels 16k + 2w, 16k + 2w + 1.  Lane = (channel,
+    // piece>>2, row, piece&3): a 16-lane group then writes 16 distinct 8-byte slots of a 128-byte window.
+    const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
+    const int s_row = (lane >> 2) & 3;
+    const int s_ch = 2 * wave + (lane >> 5);
+    const int s_x = 8 * s_piece;
+    const int s_ila = 4 * rg + s_row, s_ilb = ib0 + s_row;
+    const bool s_oka = (s_ila < HL) && (s_x < p.W);
+    const bool s_okb = (s_ilb >= 0) && (s_ilb < HL) && (s_x < p.W);
+    // buffer loads: an offset beyond num_records returns 0 (the scalar offset is not part of the range check)
+    const unsigned v_offa = s_oka ? (unsigned)((s_ch * HW + (long)(2 * s_ila + py) * p.W + s_x) * 4) : 0x80000000u;
+    const unsigned v_offb = s_okb ? (unsigned)((s_ch * HW + (long)(2 * s_ilb + py) * p.W + s_x) * 4) : 0x80000000u;
+    const unsigned nbytes = (unsigned)(p.C * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1n), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in2n), 0, nbytes, 0x00020000);
+    const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;   // this lane's chunk inside a (tile, term, parity, slot) plane
+
+    auto issue_loads = [&](LoadSet &L, int c0) {
+        if (VAR & 2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { L.a[k][h] = (u4)(0x3f800000u + lane); L.b[k][h] = (u4)(0x40000000u + lane); }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int soff = (int)((c0 + 16 * k) * HW * 4);
+            L.a[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)v_offa, soff, 0);
+            L.a[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(v_offa + 16), soff, 0);
+            L.b[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)v_offb, soff, 0);
+            L.b[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(v_offb + 16), soff, 0);
+        }
+    };
+    // 8 consecutive pixels -> (hi, lo) x (parity 0, parity 1) chunks of 4 lattice columns
+    auto split_write = [&](const u4 &q0, const u4 &q1, char *dst) {
+        if (VAR & 16) {
+            asm volatile("" ::"v"(q0), "v"(q1));
+            return;
+        }
+        const f4 x0 = __builtin_bit_cast(f4, q0), x1 = __builtin_bit_cast(f4, q1);
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
+            const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
+            const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
+            const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+            *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
+            *(FN2_LDS(u2) *)(dst + TERM + par * PARS) = (u2){l01, l23};
+        }
+    };
+    // item i (0 .. 3) of a step: (tile i>>1, slot i&1)
+    auto stage_item = [&](const LoadSet &L, int i, char *buf) {
+        char *base = buf + w_ofs + (i & 1) * 16 * CHS;
+        if (i < 2) split_write(L.a[i & 1][0], L.a[i & 1][1], base);
+        else split_write(L.b[i & 1][0], L.b[i & 1][1], base + TILE);
+    };
+
+    // ---- MFMA roles.  Transposing read: within a 16-lane group, lane 4j + c supplies the 8-byte chunk (channel row j,
+    // block row c); lane i receives, for j = 0..3, element (i & 3) of the chunk of block row i >> 2 -- i.e. pixel
+    // (row i>>2, column i&3) of the block for 4 channels.  Lane group g reads channels 4g + j and, in a second read,
+    // 16 + 4g + j: the 8 k-slots of lane group g of a 16x16x32 operand.
+    const int xpar = wave & 1;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 1);
+    const int r_base = xpar * PARS + (4 * (lane >> 4) + ((lane & 15) >> 2)) * CHS + (lane & 3) * 8;
+    auto frag = [&](const char *buf, int tile, int term, int blk) -> h8 {
+        const char *ptr = buf + r_base + tile * TILE + term * TERM + blk * 32;
+        if (VAR & 8) return (h8)((_Float16)1.0f);
+        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FN2_LDS(s4) *)(ptr));
+        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FN2_LDS(s4) *)(ptr + 16 * CHS));
+        return __builtin_bit_cast(h8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f4 acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    // One step: the MFMAs on `cur` (D = (in2 block) x (in1 block): rows = B pixels (bi = lane>>4, bj = register), columns =
+    // A pixels (lane & 15)), with the split + LDS write of the NEXT step's values (register set L -> buffer `nxt`) spread
+    // between the B blocks.  B fragments are fetched one block ahead; the sched_barriers keep the pieces where they are.
+    auto step = [&](auto role_c, const char *cur, const LoadSet &L, char *nxt, bool stage) {
+        constexpr int R = decltype(role_c)::value;
+        constexpr int NM = m_hi(R) - m_lo(R) + 1;
+        h8 ah[NAB], al[NAB];
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) { ah[ab] = frag(cur, 0, 0, a_blk(R, ab)); al[ab] = frag(cur, 0, 1, a_blk(R, ab)); }
+        h8 bh[2], bl[2];
+        bh[0] = frag(cur, 1, 0, m_lo(R)); bl[0] = frag(cur, 1, 1, m_lo(R));
+        static_for<0, NM>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, m = m_lo(R) + j;
+            constexpr int cb = j & 1, nb = cb ^ 1;
+            if constexpr (j + 1 < NM) { bh[nb] = frag(cur, 1, 0, m + 1); bl[nb] = frag(cur, 1, 1, m + 1); }
+            if (j < 4 && stage) stage_item(L, j, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (VAR & 1) {
+                asm volatile("" ::"v"(bh[cb]), "v"(bl[cb]));
+            } else {
+                // products bh*ah, bh*al, bl*ah; the A blocks alternate so that consecutive MFMAs use different accumulators
+                static_for<0, 3>([&](auto prc) {
+                    constexpr int pr = decltype(prc)::value;
+                    static_for<0, NAB>([&](auto abc) {
+                        constexpr int ab = decltype(abc)::value;
+                        constexpr int pi = pair_idx(R, ab, m);
+                        if constexpr (pi >= 0)
+                            acc[pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 2 ? bl[cb] : bh[cb], pr == 1 ? al[ab] : ah[ab], acc[pi], 0, 0, 0);
+                    });
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (VAR & 1) {
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) asm volatile("" ::"v"(ah[ab]), "v"(al[ab]));
+        }
+    };
+    auto step_dispatch = [&](const char *cur, const LoadSet &L, char *nxt, bool stage) {
+        switch (role) {
+        case 0: step(std::integral_constant<int, 0>{}, cur, L, nxt, stage); break;
+        case 1: step(std::integral_constant<int, 1>{}, cur, L, nxt, stage); break;
+        case 2: step(std::integral_constant<int, 2>{}, cur, L, nxt, stage); break;
+        default: step(std::integral_constant<int, 3>{}, cur, L, nxt, stage); break;
+        }
+    };
+
+    // ---- channel loop: buffer s&1 holds step s, register set (s+1)&1 holds step s+1 (in flight), set s&1 is free
+    const int nsteps = all_pad ? 0 : p.C / CK;   // even (C % 64 == 0) or odd
+    if (nsteps > 0) {
+        LoadSet L0, L1;
+        issue_loads(L0, 0);
+        if (nsteps > 1) issue_loads(L1, CK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_item(L0, i, smem);
+        __syncthreads();
+        for (int s = 0; s < nsteps; s += 2) {
+            if (s + 2 < nsteps) issue_loads(L0, (s + 2) * CK);
+            __builtin_amdgcn_sched_barrier(0);
+            step_dispatch(smem, L1, smem + BUF, s + 1 < nsteps);
+            __syncthreads();
+            if (s + 1 < nsteps) {
+                if (s + 3 < nsteps) issue_loads(L1, (s + 3) * CK);
+                __builtin_amdgcn_sched_barrier(0);
+                step_dispatch(smem + BUF, L0, smem, s + 2 < nsteps);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: accumulators -> LDS [plane = 4 ai + bi][ti][x], 16-byte slots rotated by 4 bi + ai
+    const int e_ai = (lane & 15) >> 2, e_aj = lane & 3, e_bi = lane >> 4;
+    const float fC = (float)p.C;
+    const bool pow2 = (p.C & (p.C - 1)) == 0;
+    const float rC = 1.0f / fC;
+    float *Os = reinterpret_cast<float *>(smem);
+    auto scatter = [&](auto role_c) {
+        constexpr int R = decltype(role_c)::value;
+        const int prow = (4 * e_ai + e_bi) * D;
+        const int rot = 4 * (4 * e_bi + e_ai);
+        static_for<0, NAB>([&](auto abc) {
+            constexpr int ab = decltype(abc)::value;
+            constexpr int a = a_blk(R, ab);
+            const int xs = (8 * a + 2 * e_aj + xpar + rot) & 63;
+            static_for<0, 7>([&](auto dmc) {
+                constexpr int dm = decltype(dmc)::value - 3;
+                constexpr int pi = pair_idx(R, ab, a + dm);
+                static_for<0, 4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;   // r = bj
+                    const int ti = 4 * dm + r - e_aj + DR;
+                    float v = 0.0f;                          // B block outside the image: zeros
+                    if constexpr (pi >= 0) v = acc[pi][r];
+                    if constexpr (dm >= -1 && dm <= 1) {
+                        Os[(prow + ti) * O_RS + xs] = v;
+                    } else {
+                        const bool ok = (ti >= 0) && (ti < D);
+                        Os[ok ? (prow + ti) * O_RS + xs : O_DUMMY + lane] = v;
+                    }
+                });
+            });
+        });
+    };
+    switch (role) {
+    case 0: scatter(std::integral_constant<int, 0>{}); break;
+    case 1: scatter(std::integral_constant<int, 1>{}); break;
+    case 2: scatter(std::integral_constant<int, 2>{}); break;
+    default: scatter(std::integral_constant<int, 3>{}); break;
+    }
+    __syncthreads();
+    // rows (plane, ti): 16 planes x 21 = 336 rows; a wave instruction stores 4 of them, 16 B per lane
+    const int xg = 4 * (lane & 15);
+    for (int row = wave * 4 + (lane >> 4); row < 16 * D; row += 32) {
+        const int pl = row / D, ti = row - pl * D;
+        const int ai = pl >> 2, bi = pl & 3;
+        const int tj = 4 * u + bi - ai;
+        const int IL = 4 * rg + ai;
+        if (tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
+        const int y = 2 * IL + py;
+        f4 val = *reinterpret_cast<const f4 *>(Os + row * O_RS + ((xg + 4 * (4 * bi + ai)) & 63));
+        const u4 bits = __builtin_bit_cast(u4, val);
+        const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
+                         ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
+        if (bad) {   // an operand did not fit an f16 (or is inf/nan): recompute those outputs in fp32
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((bits[e] & 0x7f800000u) == 0x7f800000u) val[e] = exact_corr(p, n, y, xg + e, tj, ti);
+        }
+        if (pow2) val *= rC;
+        else { val[0] /= fC; val[1] /= fC; val[2] /= fC; val[3] /= fC; }
+        if (p.slope != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * p.slope;
+        }
+        if (!(VAR & 4))
+            *reinterpret_cast<f4 *>(p.out + (long)n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = val;
+    }
+}
+
+} // namespace hf
+
+bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2)
+{
+    if (dtype != FN2_F32) return false;
+    if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md / 2 != hf::DR || (md & 1)) return false;
+    if (C % hf::CK != 0 || C < hf::CK || (H & 1) || (W % 8) != 0 || W > 64) return false;
+    if ((long)C * H * W * 4 >= 0x7fffffffL) return false;   // 32-bit buffer offsets per batch item
+    return true;
+}
+
+// variant: 0 = the kernel; other values = profiling switches (fn2_debug.h), only reachable through fn2_debug_*
+int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_bs, float slope, int B, int C, int H, int W,
+                       int variant, hipStream_t s)
+{
+    if (!aligned(in1, 16) || !aligned(in2, 16) || !aligned(out, 16) || (out_bs % 4) != 0) return FN2_EALIGN;
+    hf::Args a;
+    a.in1 = in1; a.in2 = in2; a.out = out; a.out_bs = out_bs; a.slope = slope;
+    a.C = C; a.H = H; a.W = W;
+    a.NRG = (H / 2 + 3) / 4;
+    const long ntasks = (long)B * 2 * a.NRG * hf::NU;
+    if (ntasks == 0) return FN2_OK;
+#define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+    switch (variant) {
+        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(6) FN2_HF(7) FN2_HF(9) FN2_HF(22) FN2_HF(31)
+    default: return FN2_EINVAL;
+    }
+#undef FN2_HF
+}
+
+} // namespace fn2

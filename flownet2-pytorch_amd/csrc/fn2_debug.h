@@ -1,0 +1,22 @@
+// fn2_debug.h -- profiling / ablation entry points of libflownet2_hip.so.  NOT part of the public C ABI
+// (include/flownet2_hip.h): the instantiations they select skip MFMAs, loads or stores, or dump timestamps into the
+// output, so their results are wrong by design.  Used by scripts/ (micro-benchmarks) and a few parity tests of
+// alternative tilings.
+//   forward variants : 100 .. 4999  instantiations of correlation_mfma.hip (see corr_forward_mfma_f32)
+//                      5000 + v     correlation_f16x2.hip with profiling switches v (1 no MFMA, 2 no global loads,
+//                                   4 no stores, 8 no operand reads, 16 no split / LDS staging writes)
+//   backward variants: 100 + v      instantiations of correlation_mfma_bwd.hip
+#pragma once
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int fn2_debug_correlation_forward(const void *in1, const void *in2, void *out, int dtype, int B, int C, int H, int W,
+                                  int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                  int variant, void *stream);
+int fn2_debug_correlation_backward(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,
+                                   int dtype, int B, int C, int H, int W, int pad_size, int kernel_size,
+                                   int max_displacement, int stride1, int stride2, int variant, void *stream);
+#ifdef __cplusplus
+}
+#endif

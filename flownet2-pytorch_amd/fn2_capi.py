@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libflownet2_hip.so")
 
 FN2_F32, FN2_F16, FN2_F64 = 0, 1, 2
-FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32, FN2_CORR_MFMA_BF16X3 = 0, 1, 2, 3
+FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32, FN2_CORR_MFMA_BF16X3, FN2_CORR_MFMA_F16X2 = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "fn2_strerror", "fn2_abi_version", "fn2_correlation_output_shape",
@@ -20,6 +20,9 @@ EXPORTS = [
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
     "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe",
 ]
+
+# profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design
+DEBUG_EXPORTS = ["fn2_debug_correlation_forward", "fn2_debug_correlation_backward"]
 
 _lib = None
 
@@ -36,7 +39,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.fn2_strerror.restype = ctypes.c_char_p
         _lib.fn2_strerror.argtypes = [ctypes.c_int]
-        for name in EXPORTS[1:]:
+        for name in EXPORTS[1:] + DEBUG_EXPORTS:
             getattr(_lib, name).restype = ctypes.c_int
         _lib.fn2_multiscale_workspace_bytes.restype = ctypes.c_size_t
     return _lib
@@ -74,9 +77,11 @@ def correlation_forward(in1, in2, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=No
     nOut, oH, oW = correlation_output_shape(H, W, pad, k, md, s1, s2)
     if out is None:
         out = torch.empty((B, nOut, oH, oW), dtype=in1.dtype, device=in1.device)
+    # algo >= 100: profiling instantiations, only reachable through the debug entry point
+    fn, what = ((lib().fn2_debug_correlation_forward, "fn2_debug_correlation_forward") if algo >= 100 else
+                (lib().fn2_correlation_forward_ex, "fn2_correlation_forward_ex"))
     with torch.cuda.device_of(in1):
-        check(lib().fn2_correlation_forward_ex(_p(in1), _p(in2), _p(out), _dtype_code(in1), B, C, H, W, pad, k, md, s1,
-                                               s2, algo, _stream(in1)), "fn2_correlation_forward_ex")
+        check(fn(_p(in1), _p(in2), _p(out), _dtype_code(in1), B, C, H, W, pad, k, md, s1, s2, algo, _stream(in1)), what)
     return out
 
 
@@ -99,10 +104,11 @@ def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO,
     import torch
     B, C, H, W = in1.shape
     g1, g2 = out if out is not None else (torch.empty_like(in1), torch.empty_like(in2))
+    fn, what = ((lib().fn2_debug_correlation_backward, "fn2_debug_correlation_backward") if algo >= 100 else
+                (lib().fn2_correlation_backward_ex, "fn2_correlation_backward_ex"))
     with torch.cuda.device_of(in1):
-        check(lib().fn2_correlation_backward_ex(_p(in1), _p(in2), _p(gout), _p(g1), _p(g2), _dtype_code(in1), B, C, H,
-                                                W, pad, k, md, s1, s2, algo, _stream(in1)),
-              "fn2_correlation_backward_ex")
+        check(fn(_p(in1), _p(in2), _p(gout), _p(g1), _p(g2), _dtype_code(in1), B, C, H, W, pad, k, md, s1, s2, algo,
+                 _stream(in1)), what)
     return g1, g2
 
 

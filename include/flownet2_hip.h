@@ -55,11 +55,17 @@ enum {
     FN2_CORR_AUTO = 0,    /* fastest kernel whose preconditions hold */
     FN2_CORR_DIRECT = 1,  /* one-thread-per-output kernel, any parameters / dtype */
     FN2_CORR_MFMA_F32 = 2,   /* LDS-tiled v_mfma_f32_16x16x4_f32 kernels (f32, k=1, s1=1, s2=2, pad==md): bitwise an fmaf chain */
-    FN2_CORR_MFMA_BF16X3 = 3 /* fp32 operands split exactly into 3 bf16 terms, 6 partial products on
+    FN2_CORR_MFMA_BF16X3 = 3, /* fp32 operands split exactly into 3 bf16 terms, 6 partial products on
                                 v_mfma_f32_16x16x32_bf16, fp32 accumulate -- fp32-class accuracy (same error vs fp64 as
                                 FN2_CORR_MFMA_F32).  Forward additionally needs W <= 64, C % 32 == 0, even md/2;
                                 backward needs md/2 == 10, C % 64 == 0, W % 4 == 0, 16 B aligned tensors */
+    FN2_CORR_MFMA_F16X2 = 4  /* forward only: fp32 operands split ONCE per staged value into two f16 terms (round to nearest),
+                                3 partial products on v_mfma_f32_16x16x32_f16, fp32 accumulate; outputs an operand of
+                                magnitude >= 65520 touches are recomputed in plain fp32.  Operand representation error
+                                max(2^-22 |x|, 2^-25): fp32-class.  Needs md == 20, W % 8 == 0, W <= 64, C % 32 == 0,
+                                16 B aligned tensors.  What FN2_CORR_AUTO picks for FlowNetC's cost volume. */
 };
+/* any other algo value: FN2_EINVAL */
 
 const char *fn2_strerror(int code);
 int fn2_abi_version(void);
