@@ -21,16 +21,18 @@
 // start at 4*rg - 10 + 4*u.  An A column block a meets the B column blocks a-3 .. a+3 that exist (44 block pairs per
 // parity and row-block pair instead of 48 on a grid offset by the radius).
 //
-// Work decomposition.  One workgroup (8 waves, one per CU) = one task (n, y parity, 4 lattice rows rg, B row block u):
-// A tile and B tile of 4 lattice rows x 64 pixels.  Wave w takes x parity w&1 and the two A column blocks of role w>>1:
-// {0,3}, {1,2}, {4,7}, {5,6} -- 11 block pairs each, 6 or 7 B fragments.
+// Work decomposition.  One workgroup (16 waves, one per CU) = one task (n, y parity, 4 lattice rows rg, B row block u):
+// A tile and B tile of 4 lattice rows x 64 pixels.  Waves are specialised: waves 8-15 stage (global loads, operand split,
+// LDS writes), waves 0-7 run the matrix cores: wave w takes x parity w&1 and the two A column blocks of role w>>1:
+// {0,3}, {1,2}, {4,7}, {5,6} -- 11 block pairs each, 6 or 7 B fragments.  Each SIMD hosts two waves of each kind, so the
+// split's VALU work and the MFMAs come from different instruction streams and overlap.
 //
 // Per step of 32 channels (one barrier per step, LDS double-buffered, two register sets for the loads):
 //   - the loads of step s+2 are issued (8 x 16 B per lane; buffer loads: rows outside the image come back as zeros from the
 //     range check, no select);
 //   - the values of step s+1, loaded during step s-1, are split (cvt_pk / fma_mix / cvt_pk: 2 VALU per value) and written as
 //     8-byte chunks [4 lattice columns of one parity] of the image [tile][term][parity][channel][column block][row] of
-//     the other LDS buffer -- interleaved with
+//     the other LDS buffer (staging waves) -- while
 //   - the MFMAs of step s: every wave reads its operands with ds_read_b64_tr_b16 (the LDS transpose read: 4 channel rows
 //     x 16 pixels -> per lane 4 channels of one pixel), two reads per operand, one address register and immediates for
 //     all 36 reads; 33 MFMAs.
@@ -137,14 +139,16 @@ __device__ __forceinline__ float exact_corr(const Args &p, int n, int y, int x, 
 struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
 
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no global stores, 8 no operand reads,
-//      16 no split / LDS staging writes
+//      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores)
 template <int VAR>
-__global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
+__global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_stage = wave >= 8;   // waves 8-15 load, split and fill the LDS buffers; waves 0-7 run the matrix cores
+    const int w8 = wave & 7;
 
     // ---- task decode.  Within each batch item the tasks whose B rows are all padding (they only write zeros) come last.
     const int HL = p.H >> 1;
@@ -178,74 +182,140 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
     const int ib0 = 4 * rg - DR + 4 * u;                       // first B lattice row
     const bool all_pad = (ib0 + 3 < 0) || (ib0 >= HL);
     const long HW = (long)p.H * p.W;
-    const float *in1n = p.in1 + (long)n * p.C * HW;
-    const float *in2n = p.in2 + (long)n * p.C * HW;
+    const int nsteps = all_pad ? 0 : p.C / CK;
 
-    // ---- staging roles.  A step has 32 channels x 4 rows x 8 pieces (8 pixels = 4 lattice columns of each parity) per tile;
-    // slot k (0, 1) of a tile covers channels 16k .. 16k+15: wave w channels 16k + 2w, 16k + 2w + 1.  Lane = (channel,
-    // piece>>2, row, piece&3): a 16-lane group then writes 16 distinct 8-byte slots of a 128-byte window.
-    const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
-    const int s_row = (lane >> 2) & 3;
-    const int s_ch = 2 * wave + (lane >> 5);
-    const int s_x = 8 * s_piece;
-    const int s_ila = 4 * rg + s_row, s_ilb = ib0 + s_row;
-    const bool s_oka = (s_ila < HL) && (s_x < p.W);
-    const bool s_okb = (s_ilb >= 0) && (s_ilb < HL) && (s_x < p.W);
-    // buffer loads: an offset beyond num_records returns 0 (the scalar offset is not part of the range check)
-    const unsigned v_offa = s_oka ? (unsigned)((s_ch * HW + (long)(2 * s_ila + py) * p.W + s_x) * 4) : 0x80000000u;
-    const unsigned v_offb = s_okb ? (unsigned)((s_ch * HW + (long)(2 * s_ilb + py) * p.W + s_x) * 4) : 0x80000000u;
-    const unsigned nbytes = (unsigned)(p.C * HW * 4);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1n), 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in2n), 0, nbytes, 0x00020000);
-    const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;   // this lane's chunk inside a (tile, term, parity, slot) plane
-
-    auto issue_loads = [&](LoadSet &L, int c0) {
-        if (VAR & 2) {
+    // ---- write-out of the epilogue image (all 16 waves): rows (plane, ti), 16 planes x 21 = 336 rows; a wave instruction
+    // stores 4 of them, 16 B per lane
+    const float fC = (float)p.C;
+    const bool pow2 = (p.C & (p.C - 1)) == 0;
+    const float rC = 1.0f / fC;
+    float *Os = reinterpret_cast<float *>(smem);
+    auto store_rows = [&]() {
+        if (VAR & 32) return;
+        const int xg = 4 * (lane & 15);
+        for (int row = wave * 4 + (lane >> 4); row < 16 * D; row += 64) {
+            const int pl = row / D, ti = row - pl * D;
+            const int ai = pl >> 2, bi = pl & 3;
+            const int tj = 4 * u + bi - ai;
+            const int IL = 4 * rg + ai;
+            if (tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
+            const int y = 2 * IL + py;
+            f4 val = *reinterpret_cast<const f4 *>(Os + row * O_RS + ((xg + 4 * (4 * bi + ai)) & 63));
+            if (VAR == 0) {
+                const u4 bits = __builtin_bit_cast(u4, val);
+                const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
+                                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
+                if (bad) {   // an operand did not fit an f16 (or is inf/nan): recompute those outputs in fp32
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+                    for (int e = 0; e < 4; ++e)
+                        if ((bits[e] & 0x7f800000u) == 0x7f800000u) val[e] = exact_corr(p, n, y, xg + e, tj, ti);
+                }
+            }
+            if (pow2) val *= rC;
+            else { val[0] /= fC; val[1] /= fC; val[2] /= fC; val[3] /= fC; }
+            if (p.slope != 1.0f) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) { L.a[k][h] = (u4)(0x3f800000u + lane); L.b[k][h] = (u4)(0x40000000u + lane); }
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int soff = (int)((c0 + 16 * k) * HW * 4);
-            L.a[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)v_offa, soff, 0);
-            L.a[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(v_offa + 16), soff, 0);
-            L.b[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)v_offb, soff, 0);
-            L.b[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(v_offb + 16), soff, 0);
+                for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * p.slope;
+            }
+            if (!(VAR & 4))
+                *reinterpret_cast<f4 *>(p.out + (long)n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = val;
         }
     };
-    // 8 consecutive pixels -> (hi, lo) x (parity 0, parity 1) chunks of 4 lattice columns
-    auto split_write = [&](const u4 &q0, const u4 &q1, char *dst) {
-        if (VAR & 16) {
-            asm volatile("" ::"v"(q0), "v"(q1));
-            return;
-        }
-        const f4 x0 = __builtin_bit_cast(f4, q0), x1 = __builtin_bit_cast(f4, q1);
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
-            const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
-            const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
-            const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
-            *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
-            *(FN2_LDS(u2) *)(dst + TERM + par * PARS) = (u2){l01, l23};
-        }
-    };
-    // item i (0 .. 3) of a step: (tile i>>1, slot i&1)
-    auto stage_item = [&](const LoadSet &L, int i, char *buf) {
-        char *base = buf + w_ofs + (i & 1) * 16 * CHS;
-        if (i < 2) split_write(L.a[i & 1][0], L.a[i & 1][1], base);
-        else split_write(L.b[i & 1][0], L.b[i & 1][1], base + TILE);
-    };
 
-    // ---- MFMA roles.  Transposing read: within a 16-lane group, lane 4j + c supplies the 8-byte chunk (channel row j,
-    // block row c); lane i receives, for j = 0..3, element (i & 3) of the chunk of block row i >> 2 -- i.e. pixel
-    // (row i>>2, column i&3) of the block for 4 channels.  Lane group g reads channels 4g + j and, in a second read,
-    // 16 + 4g + j: the 8 k-slots of lane group g of a 16x16x32 operand.
-    const int xpar = wave & 1;
-    const int role = __builtin_amdgcn_readfirstlane(wave >> 1);
+    if (is_stage) {
+        // ================= staging waves =================
+        // A step has 32 channels x 4 rows x 8 pieces (8 pixels = 4 lattice columns of each parity) per tile; slot k (0, 1) of
+        // a tile covers channels 16k .. 16k+15: staging wave w channels 16k + 2w, 16k + 2w + 1.  Lane = (channel, piece>>2,
+        // row, piece&3): a 16-lane group then writes 16 distinct 8-byte slots of a 128-byte window.
+        const float *in1n = p.in1 + (long)n * p.C * HW;
+        const float *in2n = p.in2 + (long)n * p.C * HW;
+        const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
+        const int s_row = (lane >> 2) & 3;
+        const int s_ch = 2 * w8 + (lane >> 5);
+        const int s_x = 8 * s_piece;
+        const int s_ila = 4 * rg + s_row, s_ilb = ib0 + s_row;
+        const bool s_oka = (s_ila < HL) && (s_x < p.W);
+        const bool s_okb = (s_ilb >= 0) && (s_ilb < HL) && (s_x < p.W);
+        // buffer loads: an offset beyond num_records returns 0 (the scalar offset is not part of the range check)
+        const unsigned v_offa = s_oka ? (unsigned)((s_ch * HW + (long)(2 * s_ila + py) * p.W + s_x) * 4) : 0x80000000u;
+        const unsigned v_offb = s_okb ? (unsigned)((s_ch * HW + (long)(2 * s_ilb + py) * p.W + s_x) * 4) : 0x80000000u;
+        const unsigned nbytes = (unsigned)(p.C * HW * 4);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1n), 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in2n), 0, nbytes, 0x00020000);
+        const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;   // this lane's chunk inside a (tile, term, parity, slot) plane
+
+        auto issue_loads = [&](LoadSet &L, int c0) {
+            if (VAR & 2) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { L.a[k][h] = (u4)(0x3f800000u + lane); L.b[k][h] = (u4)(0x40000000u + lane); }
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int soff = (int)((c0 + 16 * k) * HW * 4);
+                L.a[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)v_offa, soff, 0);
+                L.a[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(v_offa + 16), soff, 0);
+                L.b[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)v_offb, soff, 0);
+                L.b[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(v_offb + 16), soff, 0);
+            }
+        };
+        // 8 consecutive pixels -> (hi, lo) x (parity 0, parity 1) chunks of 4 lattice columns
+        auto split_write = [&](const u4 &q0, const u4 &q1, char *dst) {
+            if (VAR & 16) {
+                asm volatile("" ::"v"(q0), "v"(q1));
+                return;
+            }
+            const f4 x0 = __builtin_bit_cast(f4, q0), x1 = __builtin_bit_cast(f4, q1);
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
+                const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
+                const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
+                const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+                *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
+                *(FN2_LDS(u2) *)(dst + TERM + par * PARS) = (u2){l01, l23};
+            }
+        };
+        auto stage_write = [&](const LoadSet &L, char *buf) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                split_write(L.a[k][0], L.a[k][1], buf + w_ofs + k * 16 * CHS);
+                split_write(L.b[k][0], L.b[k][1], buf + w_ofs + k * 16 * CHS + TILE);
+            }
+        };
+
+        // buffer s&1 holds step s; register set (s+1)&1 holds step s+1 (in flight), set s&1 is free for step s+2
+        if (nsteps > 0) {
+            LoadSet L0, L1;
+            issue_loads(L0, 0);
+            if (nsteps > 1) issue_loads(L1, CK);
+            stage_write(L0, smem);
+            __syncthreads();
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 2 < nsteps) issue_loads(L0, (s + 2) * CK);
+                if (s + 1 < nsteps) stage_write(L1, smem + BUF);
+                __syncthreads();
+                if (s + 1 < nsteps) {
+                    if (s + 3 < nsteps) issue_loads(L1, (s + 3) * CK);
+                    if (s + 2 < nsteps) stage_write(L0, smem);
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();   // the epilogue image is complete
+        store_rows();
+        return;
+    }
+
+    // ================= matrix-core waves =================
+    // Transposing read: within a 16-lane group, lane 4j + c supplies the 8-byte chunk (channel row j, block row c); lane i
+    // receives, for j = 0..3, element (i & 3) of the chunk of block row i >> 2 -- i.e. pixel (row i>>2, column i&3) of the
+    // block for 4 channels.  Lane group g reads channels 4g + j and, in a second read, 16 + 4g + j: the 8 k-slots of lane
+    // group g of a 16x16x32 operand.
+    const int xpar = w8 & 1;
+    const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
     const int r_base = xpar * PARS + (4 * (lane >> 4) + ((lane & 15) >> 2)) * CHS + (lane & 3) * 8;
     auto frag = [&](const char *buf, int tile, int term, int blk) -> h8 {
         const char *ptr = buf + r_base + tile * TILE + term * TERM + blk * 32;
@@ -259,10 +329,9 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    // One step: the MFMAs on `cur` (D = (in2 block) x (in1 block): rows = B pixels (bi = lane>>4, bj = register), columns =
-    // A pixels (lane & 15)), with the split + LDS write of the NEXT step's values (register set L -> buffer `nxt`) spread
-    // between the B blocks.  B fragments are fetched one block ahead; the sched_barriers keep the pieces where they are.
-    auto step = [&](auto role_c, const char *cur, const LoadSet &L, char *nxt, bool stage) {
+    // One step: D = (in2 block) x (in1 block): rows = B pixels (bi = lane>>4, bj = register), columns = A pixels (lane & 15).
+    // B fragments are fetched one block ahead of their MFMAs.
+    auto step = [&](auto role_c, const char *cur) {
         constexpr int R = decltype(role_c)::value;
         constexpr int NM = m_hi(R) - m_lo(R) + 1;
         h8 ah[NAB], al[NAB];
@@ -274,8 +343,6 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
             constexpr int j = decltype(jc)::value, m = m_lo(R) + j;
             constexpr int cb = j & 1, nb = cb ^ 1;
             if constexpr (j + 1 < NM) { bh[nb] = frag(cur, 1, 0, m + 1); bl[nb] = frag(cur, 1, 1, m + 1); }
-            if (j < 4 && stage) stage_item(L, j, nxt);
-            __builtin_amdgcn_sched_barrier(0);
             if (VAR & 1) {
                 asm volatile("" ::"v"(bh[cb]), "v"(bl[cb]));
             } else {
@@ -290,40 +357,27 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
                     });
                 });
             }
-            __builtin_amdgcn_sched_barrier(0);
         });
         if (VAR & 1) {
 #pragma unroll
             for (int ab = 0; ab < NAB; ++ab) asm volatile("" ::"v"(ah[ab]), "v"(al[ab]));
         }
     };
-    auto step_dispatch = [&](const char *cur, const LoadSet &L, char *nxt, bool stage) {
+    auto step_dispatch = [&](const char *cur) {
         switch (role) {
-        case 0: step(std::integral_constant<int, 0>{}, cur, L, nxt, stage); break;
-        case 1: step(std::integral_constant<int, 1>{}, cur, L, nxt, stage); break;
-        case 2: step(std::integral_constant<int, 2>{}, cur, L, nxt, stage); break;
-        default: step(std::integral_constant<int, 3>{}, cur, L, nxt, stage); break;
+        case 0: step(std::integral_constant<int, 0>{}, cur); break;
+        case 1: step(std::integral_constant<int, 1>{}, cur); break;
+        case 2: step(std::integral_constant<int, 2>{}, cur); break;
+        default: step(std::integral_constant<int, 3>{}, cur); break;
         }
     };
-
-    // ---- channel loop: buffer s&1 holds step s, register set (s+1)&1 holds step s+1 (in flight), set s&1 is free
-    const int nsteps = all_pad ? 0 : p.C / CK;   // even (C % 64 == 0) or odd
     if (nsteps > 0) {
-        LoadSet L0, L1;
-        issue_loads(L0, 0);
-        if (nsteps > 1) issue_loads(L1, CK);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage_item(L0, i, smem);
         __syncthreads();
         for (int s = 0; s < nsteps; s += 2) {
-            if (s + 2 < nsteps) issue_loads(L0, (s + 2) * CK);
-            __builtin_amdgcn_sched_barrier(0);
-            step_dispatch(smem, L1, smem + BUF, s + 1 < nsteps);
+            step_dispatch(smem);
             __syncthreads();
             if (s + 1 < nsteps) {
-                if (s + 3 < nsteps) issue_loads(L1, (s + 3) * CK);
-                __builtin_amdgcn_sched_barrier(0);
-                step_dispatch(smem + BUF, L0, smem, s + 2 < nsteps);
+                step_dispatch(smem + BUF);
                 __syncthreads();
             }
         }
@@ -331,10 +385,6 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
 
     // ---- epilogue: accumulators -> LDS [plane = 4 ai + bi][ti][x], 16-byte slots rotated by 4 bi + ai
     const int e_ai = (lane & 15) >> 2, e_aj = lane & 3, e_bi = lane >> 4;
-    const float fC = (float)p.C;
-    const bool pow2 = (p.C & (p.C - 1)) == 0;
-    const float rC = 1.0f / fC;
-    float *Os = reinterpret_cast<float *>(smem);
     auto scatter = [&](auto role_c) {
         constexpr int R = decltype(role_c)::value;
         const int prow = (4 * e_ai + e_bi) * D;
@@ -361,40 +411,19 @@ __global__ __launch_bounds__(512, 2) void corr_fwd_f16x2(Args p)
             });
         });
     };
-    switch (role) {
-    case 0: scatter(std::integral_constant<int, 0>{}); break;
-    case 1: scatter(std::integral_constant<int, 1>{}); break;
-    case 2: scatter(std::integral_constant<int, 2>{}); break;
-    default: scatter(std::integral_constant<int, 3>{}); break;
+    if (!(VAR & 32)) {
+        switch (role) {
+        case 0: scatter(std::integral_constant<int, 0>{}); break;
+        case 1: scatter(std::integral_constant<int, 1>{}); break;
+        case 2: scatter(std::integral_constant<int, 2>{}); break;
+        default: scatter(std::integral_constant<int, 3>{}); break;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(acc[i]));
     }
     __syncthreads();
-    // rows (plane, ti): 16 planes x 21 = 336 rows; a wave instruction stores 4 of them, 16 B per lane
-    const int xg = 4 * (lane & 15);
-    for (int row = wave * 4 + (lane >> 4); row < 16 * D; row += 32) {
-        const int pl = row / D, ti = row - pl * D;
-        const int ai = pl >> 2, bi = pl & 3;
-        const int tj = 4 * u + bi - ai;
-        const int IL = 4 * rg + ai;
-        if (tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
-        const int y = 2 * IL + py;
-        f4 val = *reinterpret_cast<const f4 *>(Os + row * O_RS + ((xg + 4 * (4 * bi + ai)) & 63));
-        const u4 bits = __builtin_bit_cast(u4, val);
-        const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
-                         ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
-        if (bad) {   // an operand did not fit an f16 (or is inf/nan): recompute those outputs in fp32
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((bits[e] & 0x7f800000u) == 0x7f800000u) val[e] = exact_corr(p, n, y, xg + e, tj, ti);
-        }
-        if (pow2) val *= rC;
-        else { val[0] /= fC; val[1] /= fC; val[2] /= fC; val[3] /= fC; }
-        if (p.slope != 1.0f) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * p.slope;
-        }
-        if (!(VAR & 4))
-            *reinterpret_cast<f4 *>(p.out + (long)n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = val;
-    }
+    store_rows();
 }
 
 } // namespace hf
@@ -419,9 +448,9 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     a.NRG = (H / 2 + 3) / 4;
     const long ntasks = (long)B * 2 * a.NRG * hf::NU;
     if (ntasks == 0) return FN2_OK;
-#define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3((unsigned)ntasks), dim3(512), 0, s, a); return launch_status();
+#define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3((unsigned)ntasks), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(6) FN2_HF(7) FN2_HF(9) FN2_HF(22) FN2_HF(31)
+        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(63)
     default: return FN2_EINVAL;
     }
 #undef FN2_HF
