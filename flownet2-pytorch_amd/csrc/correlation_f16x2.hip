@@ -66,13 +66,17 @@ constexpr int O_RS = 64;                          // epilogue row stride (floats
 constexpr int O_DUMMY = 16 * D * O_RS;            // sink row for out-of-band entries
 static_assert((O_DUMMY + 64) * 4 <= LDS_BYTES, "epilogue image must fit the operand buffers");
 
+constexpr int MAX_TAB = 768;                      // tasks per batch item the kernel-argument table holds (H <= 512)
+
 struct Args {
     const float *in1, *in2;
     float *out;
     long out_bs;     // elements between batch items of `out`
     float slope;     // fused LeakyReLU slope (1 = none)
-    int C, H, W;     // H even, W % 8 == 0, W <= 64
-    int NRG;         // row groups per parity
+    int B, C, H, W;  // H even, W % 8 == 0, W <= 64, C % 64 == 0
+    int R_item, P_item;        // tasks per batch item whose B rows meet the image / lie entirely in the padding
+    unsigned magic_r, magic_p; // ceil(2^32 / R_item), ceil(2^32 / P_item)
+    unsigned tab[MAX_TAB / 2];     // 16-bit entries (rg << 4 | py << 3 | u): the R_item real, then the P_item zero-only tasks of an item
 };
 
 // wave roles: A column blocks of role r, and the B column blocks they meet
@@ -138,8 +142,36 @@ __device__ __forceinline__ float exact_corr(const Args &p, int n, int y, int x, 
 
 struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
 
+// A task = (batch item n, y parity, row group rg of 4 lattice rows, B row block u).  "Real" tasks have B rows inside the
+// image; the others only write zeros.  Tasks are numbered item-major, separately for the two kinds; the (py, rg, u) of the
+// k-th task of a kind within an item comes from a table the launcher puts into the kernel arguments (all scalar work).
+struct Task { int n, py, rg, u, real; };
+
+__device__ __forceinline__ Task decode_task(const Args &p, bool real, int k)
+{
+    const unsigned per = real ? (unsigned)p.R_item : (unsigned)p.P_item;
+    const unsigned n = __umulhi((unsigned)k, real ? p.magic_r : p.magic_p);   // k / per (exact for k < 2^16, checked by the launcher)
+    const unsigned r = (unsigned)k - n * per;
+    // dword loads with a wave-uniform index: scalar loads from the kernel-argument segment
+    const unsigned i = __builtin_amdgcn_readfirstlane((real ? 0u : (unsigned)p.R_item) + r);
+    const unsigned e = (p.tab[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
+    Task t;
+    t.real = real ? 1 : 0;
+    t.n = __builtin_amdgcn_readfirstlane((int)n);
+    t.u = __builtin_amdgcn_readfirstlane((int)(e & 7u));
+    t.py = __builtin_amdgcn_readfirstlane((int)((e >> 3) & 1u));
+    t.rg = __builtin_amdgcn_readfirstlane((int)(e >> 4));
+    return t;
+}
+
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no global stores, 8 no operand reads,
 //      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores)
+//
+// Persistent: the grid is 8 x G workgroups (G <= 32, one per CU); workgroup b belongs to stream b % 8 (= its XCD, so the
+// tasks of one batch item share an L2) and walks a fixed list: every G-th real task of the stream's share, then its share
+// of the zero-only tasks (handed to the workgroups with one real task fewer).  The staging waves run ahead: the loads of
+// the next task's first two steps are issued during the last two steps of the current one, so only the first task of a
+// workgroup sees the global-memory latency, and the output rows of a task drain while the next one is computed.
 template <int VAR>
 __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 {
@@ -149,40 +181,25 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_stage = wave >= 8;   // waves 8-15 load, split and fill the LDS buffers; waves 0-7 run the matrix cores
     const int w8 = wave & 7;
-
-    // ---- task decode.  Within each batch item the tasks whose B rows are all padding (they only write zeros) come last.
     const int HL = p.H >> 1;
-    unsigned t = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_item = 2 * p.NRG * NU;
-    const int n = (int)(t / per_item);
-    int idx = (int)(t % per_item), u = 0, rg = 0, py = 0;
-    {
-        auto ulo = [&](int g) { const int v = DR - 3 - 4 * g; return v <= 0 ? 0 : (v + 3) / 4; };
-        auto uhi = [&](int g) { const int v = (HL - 1 + DR - 4 * g) / 4; return v < NU - 1 ? v : NU - 1; };
-        int R = 0;
-        for (int g = 0; g < p.NRG; ++g) { const int c = uhi(g) - ulo(g) + 1; R += c > 0 ? c : 0; }
-        const bool real = idx < 2 * R;
-        const int per_par = real ? R : p.NRG * NU - R;
-        int r = real ? idx : idx - 2 * R;
-        py = r / per_par; r -= py * per_par;
-        for (int g = 0; g < p.NRG; ++g) {
-            const int lo = ulo(g), hi = uhi(g);
-            const int c = hi - lo + 1 > 0 ? hi - lo + 1 : 0;
-            const int k = real ? c : NU - c;
-            if (r < k) {
-                rg = g;
-                u = real ? lo + r : (c == 0 ? r : (r < lo ? r : hi + 1 + (r - lo)));
-                break;
-            }
-            r -= k;
-        }
-    }
-    py = __builtin_amdgcn_readfirstlane(py); rg = __builtin_amdgcn_readfirstlane(rg); u = __builtin_amdgcn_readfirstlane(u);
-
-    const int ib0 = 4 * rg - DR + 4 * u;                       // first B lattice row
-    const bool all_pad = (ib0 + 3 < 0) || (ib0 >= HL);
     const long HW = (long)p.H * p.W;
-    const int nsteps = all_pad ? 0 : p.C / CK;
+    const int nsteps = p.C / CK;       // even
+
+    // ---- this workgroup's task list
+    const int G = gridDim.x >> 3, strm = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int Rtot = p.B * p.R_item, Ptot = p.B * p.P_item;
+    const int r0 = (int)((long)strm * Rtot / 8), r1 = (int)((long)(strm + 1) * Rtot / 8);
+    const int q0 = (int)((long)strm * Ptot / 8), q1 = (int)((long)(strm + 1) * Ptot / 8);
+    const int Rc = r1 - r0, Pc = q1 - q0;
+    const int n_real = (Rc - j + G - 1) / G > 0 ? (Rc - j + G - 1) / G : 0;
+    const int rem = Rc % G;                                   // workgroups rem .. G-1 have one real task fewer
+    const int pgrp = rem == 0 ? G : G - rem, pj = rem == 0 ? j : j - rem;
+    const int n_pad = (pj >= 0 && Pc - pj > 0) ? (Pc - pj + pgrp - 1) / pgrp : 0;
+    const int n_tasks = n_real + n_pad;
+    auto get_task = [&](int i) -> Task {
+        if (i < n_real) return decode_task(p, true, r0 + j + G * i);
+        return decode_task(p, false, q0 + pj + pgrp * (i - n_real));
+    };
 
     // ---- write-out of the epilogue image (all 16 waves): rows (plane, ti), 16 planes x 21 = 336 rows; a wave instruction
     // stores 4 of them, 16 B per lane
@@ -190,25 +207,35 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const float rC = 1.0f / fC;
     float *Os = reinterpret_cast<float *>(smem);
-    auto store_rows = [&]() {
+    auto store_rows = [&](const Task &tk) {
         if (VAR & 32) return;
-        const int xg = 4 * (lane & 15);
-        for (int row = wave * 4 + (lane >> 4); row < 16 * D; row += 64) {
+        // the row geometry depends on the lane only; the opaque copy keeps it from being hoisted out of the task loop
+        // (and spilled) by loop-invariant code motion
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int xg = 4 * (ln & 15);
+        for (int row = wave * 4 + (ln >> 4); row < 16 * D; row += 64) {
             const int pl = row / D, ti = row - pl * D;
             const int ai = pl >> 2, bi = pl & 3;
-            const int tj = 4 * u + bi - ai;
-            const int IL = 4 * rg + ai;
+            const int tj = 4 * tk.u + bi - ai;
+            const int IL = 4 * tk.rg + ai;
             if (tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
-            const int y = 2 * IL + py;
+            const int y = 2 * IL + tk.py;
             f4 val = *reinterpret_cast<const f4 *>(Os + row * O_RS + ((xg + 4 * (4 * bi + ai)) & 63));
             if (VAR == 0) {
                 const u4 bits = __builtin_bit_cast(u4, val);
                 const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
                                  ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
                 if (bad) {   // an operand did not fit an f16 (or is inf/nan): recompute those outputs in fp32
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if ((bits[e] & 0x7f800000u) == 0x7f800000u) val[e] = exact_corr(p, n, y, xg + e, tj, ti);
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e) {
+                        const float ex = exact_corr(p, tk.n, y, xg + e, tj, ti);
+                        const unsigned be = e == 0 ? bits[0] : e == 1 ? bits[1] : e == 2 ? bits[2] : bits[3];
+                        if ((be & 0x7f800000u) == 0x7f800000u) {
+                            val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
+                            val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
+                        }
+                    }
                 }
             }
             if (pow2) val *= rC;
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                 for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * p.slope;
             }
             if (!(VAR & 4))
-                *reinterpret_cast<f4 *>(p.out + (long)n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = val;
+                *reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = val;
         }
     };
 
@@ -227,23 +254,26 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         // A step has 32 channels x 4 rows x 8 pieces (8 pixels = 4 lattice columns of each parity) per tile; slot k (0, 1) of
         // a tile covers channels 16k .. 16k+15: staging wave w channels 16k + 2w, 16k + 2w + 1.  Lane = (channel, piece>>2,
         // row, piece&3): a 16-lane group then writes 16 distinct 8-byte slots of a 128-byte window.
-        const float *in1n = p.in1 + (long)n * p.C * HW;
-        const float *in2n = p.in2 + (long)n * p.C * HW;
         const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
         const int s_row = (lane >> 2) & 3;
         const int s_ch = 2 * w8 + (lane >> 5);
         const int s_x = 8 * s_piece;
-        const int s_ila = 4 * rg + s_row, s_ilb = ib0 + s_row;
-        const bool s_oka = (s_ila < HL) && (s_x < p.W);
-        const bool s_okb = (s_ilb >= 0) && (s_ilb < HL) && (s_x < p.W);
-        // buffer loads: an offset beyond num_records returns 0 (the scalar offset is not part of the range check)
-        const unsigned v_offa = s_oka ? (unsigned)((s_ch * HW + (long)(2 * s_ila + py) * p.W + s_x) * 4) : 0x80000000u;
-        const unsigned v_offb = s_okb ? (unsigned)((s_ch * HW + (long)(2 * s_ilb + py) * p.W + s_x) * 4) : 0x80000000u;
-        const unsigned nbytes = (unsigned)(p.C * HW * 4);
-        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1n), 0, nbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in2n), 0, nbytes, 0x00020000);
         const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;   // this lane's chunk inside a (tile, term, parity, slot) plane
-
+        const unsigned nbytes = (unsigned)(p.C * HW * 4);
+        // per-task load context: buffer descriptors of the batch item, per-lane offsets.  Buffer loads: an offset beyond
+        // num_records returns 0 (the scalar offset is not part of the range check) -- rows outside the image need no select.
+        __amdgpu_buffer_rsrc_t rs1, rs2;
+        unsigned v_offa, v_offb;
+        auto set_ctx = [&](const Task &tk, bool valid) {
+            const int ib0 = 4 * tk.rg - DR + 4 * tk.u;
+            const int s_ila = 4 * tk.rg + s_row, s_ilb = ib0 + s_row;
+            const bool s_oka = valid && (s_ila < HL) && (s_x < p.W);
+            const bool s_okb = valid && (s_ilb >= 0) && (s_ilb < HL) && (s_x < p.W);
+            v_offa = s_oka ? (unsigned)((s_ch * HW + (long)(2 * s_ila + tk.py) * p.W + s_x) * 4) : 0x80000000u;
+            v_offb = s_okb ? (unsigned)((s_ch * HW + (long)(2 * s_ilb + tk.py) * p.W + s_x) * 4) : 0x80000000u;
+            rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in1 + (long)tk.n * p.C * HW), 0, nbytes, 0x00020000);
+            rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in2 + (long)tk.n * p.C * HW), 0, nbytes, 0x00020000);
+        };
         auto issue_loads = [&](LoadSet &L, int c0) {
             if (VAR & 2) {
 #pragma unroll
@@ -280,32 +310,53 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         };
         auto stage_write = [&](const LoadSet &L, char *buf) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 2; ++k) {   // one item at a time: interleaving them costs registers this branch does not have
                 split_write(L.a[k][0], L.a[k][1], buf + w_ofs + k * 16 * CHS);
+                __builtin_amdgcn_sched_barrier(0);
                 split_write(L.b[k][0], L.b[k][1], buf + w_ofs + k * 16 * CHS + TILE);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
 
-        // buffer s&1 holds step s; register set (s+1)&1 holds step s+1 (in flight), set s&1 is free for step s+2
-        if (nsteps > 0) {
-            LoadSet L0, L1;
+        // Invariant at the top of a real task: its steps 0 and 1 are in flight in L0 and L1.  During step s buffer s&1 is
+        // being read, register set (s+1)&1 holds step s+1 and set s&1 is free: it receives step s+2 of this task, or -- in
+        // the last two steps -- step s+2-nsteps of the next real task.
+        LoadSet L0, L1;
+        if (n_real > 0) {
+            set_ctx(get_task(0), true);
             issue_loads(L0, 0);
-            if (nsteps > 1) issue_loads(L1, CK);
+            issue_loads(L1, CK);
+        }
+        for (int it = 0; it < n_real; ++it) {
+            const Task tk = get_task(it);
+            const bool has_next = it + 1 < n_real;
             stage_write(L0, smem);
             __syncthreads();
-            for (int s = 0; s < nsteps; s += 2) {
-                if (s + 2 < nsteps) issue_loads(L0, (s + 2) * CK);
-                if (s + 1 < nsteps) stage_write(L1, smem + BUF);
+            for (int s = 0; s + 2 < nsteps; s += 2) {
+                issue_loads(L0, (s + 2) * CK);
+                stage_write(L1, smem + BUF);
                 __syncthreads();
-                if (s + 1 < nsteps) {
-                    if (s + 3 < nsteps) issue_loads(L1, (s + 3) * CK);
-                    if (s + 2 < nsteps) stage_write(L0, smem);
-                    __syncthreads();
-                }
+                issue_loads(L1, (s + 3) * CK);
+                stage_write(L0, smem);
+                __syncthreads();
             }
+            // last two steps: the free register sets receive steps 0 and 1 of the next real task (after the last one the
+            // offsets are out of range: the loads return zeros without touching memory)
+            set_ctx(get_task(has_next ? it + 1 : it), has_next);
+            issue_loads(L0, 0);
+            stage_write(L1, smem + BUF);
+            __syncthreads();
+            issue_loads(L1, CK);
+            __syncthreads();
+            __syncthreads();   // the epilogue image is complete
+            store_rows(tk);
+            __syncthreads();   // ... and has been read: the buffers are free
         }
-        __syncthreads();   // the epilogue image is complete
-        store_rows();
+        for (int it = n_real; it < n_tasks; ++it) {   // zero-only tasks
+            __syncthreads();
+            store_rows(get_task(it));
+            __syncthreads();
+        }
         return;
     }
 
@@ -326,9 +377,6 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     };
 
     f4 acc[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-
     // One step: D = (in2 block) x (in1 block): rows = B pixels (bi = lane>>4, bj = register), columns = A pixels (lane & 15).
     // B fragments are fetched one block ahead of their MFMAs.
     auto step = [&](auto role_c, const char *cur) {
@@ -340,9 +388,9 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         h8 bh[2], bl[2];
         bh[0] = frag(cur, 1, 0, m_lo(R)); bl[0] = frag(cur, 1, 1, m_lo(R));
         static_for<0, NM>([&](auto jc) {
-            constexpr int j = decltype(jc)::value, m = m_lo(R) + j;
-            constexpr int cb = j & 1, nb = cb ^ 1;
-            if constexpr (j + 1 < NM) { bh[nb] = frag(cur, 1, 0, m + 1); bl[nb] = frag(cur, 1, 1, m + 1); }
+            constexpr int jj = decltype(jc)::value, m = m_lo(R) + jj;
+            constexpr int cb = jj & 1, nb = cb ^ 1;
+            if constexpr (jj + 1 < NM) { bh[nb] = frag(cur, 1, 0, m + 1); bl[nb] = frag(cur, 1, 1, m + 1); }
             if (VAR & 1) {
                 asm volatile("" ::"v"(bh[cb]), "v"(bl[cb]));
             } else {
@@ -371,22 +419,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         default: step(std::integral_constant<int, 3>{}, cur); break;
         }
     };
-    if (nsteps > 0) {
-        __syncthreads();
-        for (int s = 0; s < nsteps; s += 2) {
-            step_dispatch(smem);
-            __syncthreads();
-            if (s + 1 < nsteps) {
-                step_dispatch(smem + BUF);
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- epilogue: accumulators -> LDS [plane = 4 ai + bi][ti][x], 16-byte slots rotated by 4 bi + ai
-    const int e_ai = (lane & 15) >> 2, e_aj = lane & 3, e_bi = lane >> 4;
+    // epilogue, first half: accumulators -> LDS [plane = 4 ai + bi][ti][x], 16-byte slots rotated by 4 bi + ai
     auto scatter = [&](auto role_c) {
         constexpr int R = decltype(role_c)::value;
+        int ln = lane;   // opaque copy: see store_rows
+        asm volatile("" : "+v"(ln));
+        const int e_ai = (ln & 15) >> 2, e_aj = ln & 3, e_bi = ln >> 4;
         const int prow = (4 * e_ai + e_bi) * D;
         const int rot = 4 * (4 * e_bi + e_ai);
         static_for<0, NAB>([&](auto abc) {
@@ -405,25 +443,44 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                         Os[(prow + ti) * O_RS + xs] = v;
                     } else {
                         const bool ok = (ti >= 0) && (ti < D);
-                        Os[ok ? (prow + ti) * O_RS + xs : O_DUMMY + lane] = v;
+                        Os[ok ? (prow + ti) * O_RS + xs : O_DUMMY + ln] = v;
                     }
                 });
             });
         });
     };
-    if (!(VAR & 32)) {
-        switch (role) {
-        case 0: scatter(std::integral_constant<int, 0>{}); break;
-        case 1: scatter(std::integral_constant<int, 1>{}); break;
-        case 2: scatter(std::integral_constant<int, 2>{}); break;
-        default: scatter(std::integral_constant<int, 3>{}); break;
-        }
-    } else {
+
+    auto epilogue = [&](const Task &tk) {
+        if (!(VAR & 32)) {
+            switch (role) {
+            case 0: scatter(std::integral_constant<int, 0>{}); break;
+            case 1: scatter(std::integral_constant<int, 1>{}); break;
+            case 2: scatter(std::integral_constant<int, 2>{}); break;
+            default: scatter(std::integral_constant<int, 3>{}); break;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(acc[i]));
+            for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(acc[i]));
+        }
+        __syncthreads();
+        store_rows(tk);
+        __syncthreads();
+    };
+    for (int it = 0; it < n_real; ++it) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+        for (int s = 0; s < nsteps; s += 2) {
+            step_dispatch(smem);
+            __syncthreads();
+            step_dispatch(smem + BUF);
+            __syncthreads();
+        }
+        epilogue(get_task(it));
     }
-    __syncthreads();
-    store_rows();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it));   // zero-only tasks
 }
 
 } // namespace hf
@@ -432,7 +489,7 @@ bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int m
 {
     if (dtype != FN2_F32) return false;
     if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md / 2 != hf::DR || (md & 1)) return false;
-    if (C % hf::CK != 0 || C < hf::CK || (H & 1) || (W % 8) != 0 || W > 64) return false;
+    if (C % (2 * hf::CK) != 0 || C < 2 * hf::CK || (H & 1) || (W % 8) != 0 || W > 64) return false;
     if ((long)C * H * W * 4 >= 0x7fffffffL) return false;   // 32-bit buffer offsets per batch item
     return true;
 }
@@ -444,11 +501,33 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     if (!aligned(in1, 16) || !aligned(in2, 16) || !aligned(out, 16) || (out_bs % 4) != 0) return FN2_EALIGN;
     hf::Args a;
     a.in1 = in1; a.in2 = in2; a.out = out; a.out_bs = out_bs; a.slope = slope;
-    a.C = C; a.H = H; a.W = W;
-    a.NRG = (H / 2 + 3) / 4;
-    const long ntasks = (long)B * 2 * a.NRG * hf::NU;
+    a.B = B; a.C = C; a.H = H; a.W = W;
+    const int HL = H / 2, NRG = (HL + 3) / 4;
+    if (2 * NRG * hf::NU > hf::MAX_TAB) return FN2_EUNSUPPORTED;
+    // table of the (py, rg, u) combinations of one batch item: those whose B rows 4rg - 10 + 4u .. +3 meet [0, HL) first
+    int R = 0, P = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int py = 0; py < 2; ++py)
+            for (int g = 0; g < NRG; ++g)
+                for (int u = 0; u < hf::NU; ++u) {
+                    const int ib0 = 4 * g - hf::DR + 4 * u;
+                    const bool real = ib0 + 3 >= 0 && ib0 < HL;
+                    if (real != (pass == 0)) continue;
+                    const unsigned e = (unsigned)((g << 4) | (py << 3) | u), i = (unsigned)(R + P);
+                    a.tab[i >> 1] = (i & 1u) ? (a.tab[i >> 1] | (e << 16)) : e;
+                    if (real) ++R; else ++P;
+                }
+    a.R_item = R; a.P_item = P;
+    a.magic_r = R ? (unsigned)((0x100000000ull + R - 1) / R) : 0u;
+    a.magic_p = P ? (unsigned)((0x100000000ull + P - 1) / P) : 0u;
+    if ((long)B * (R > P ? R : P) >= 65536) return FN2_EUNSUPPORTED;   // the magic-number division is exact below 2^16
+    const long ntasks = (long)B * (R + P);
     if (ntasks == 0) return FN2_OK;
-#define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3((unsigned)ntasks), dim3(1024), 0, s, a); return launch_status();
+    if (ntasks > 0x3fffffffL) return FN2_EINVAL;
+    // persistent grid: 8 streams (one per XCD) x G workgroups, one workgroup per CU
+    const long per_stream = (ntasks + 7) / 8;
+    const int G = per_stream < 32 ? (int)per_stream : 32;
+#define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3(8u * G), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
         FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(63)
     default: return FN2_EINVAL;
