@@ -202,3 +202,5 @@ extern "C" int fn2_debug_correlation_backward(const void *in1, const void *in2, 
     return corr_backward_impl(in1, in2, grad_out, grad_in1, grad_in2, dtype, B, C, H, W, pad_size, kernel_size,
                               max_displacement, stride1, stride2, variant, true, stream);
 }
+
+extern "C" void fn2_debug_set_buffer(void *device_ptr) { fn2::corr_f16x2_set_debug_buffer(device_ptr); }

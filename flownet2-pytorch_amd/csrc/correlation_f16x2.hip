@@ -76,6 +76,7 @@ struct Args {
     int B, C, H, W;  // H even, W % 8 == 0, W <= 64, C % 64 == 0
     int R_item, P_item;        // tasks per batch item whose B rows meet the image / lie entirely in the padding
     unsigned magic_r, magic_p; // ceil(2^32 / R_item), ceil(2^32 / P_item)
+    unsigned long long *dbg;   // profiling variant 64 only: where the s_memtime stamps go (fn2_debug_set_buffer)
     unsigned tab[MAX_TAB / 2];     // 16-bit entries (rg << 4 | py << 3 | u): the R_item real, then the P_item zero-only tasks of an item
 };
 
@@ -165,7 +166,7 @@ __device__ __forceinline__ Task decode_task(const Args &p, bool real, int k)
 }
 
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no global stores, 8 no operand reads,
-//      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores)
+//      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores), 64 s_memtime stamps dumped over the output
 //
 // Persistent: the grid is 8 x G workgroups (G <= 32, one per CU); workgroup b belongs to stream b % 8 (= its XCD, so the
 // tasks of one batch item share an L2) and walks a fixed list: every G-th real task of the stream's share, then its share
@@ -179,11 +180,25 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_stage = wave >= 8;   // waves 8-15 load, split and fill the LDS buffers; waves 0-7 run the matrix cores
+    const bool is_stage = wave < 8;    // waves 0-7 (dispatched first) load, split and fill the LDS buffers; waves 8-15 run the matrix cores
     const int w8 = wave & 7;
     const int HL = p.H >> 1;
     const long HW = (long)p.H * p.W;
     const int nsteps = p.C / CK;       // even
+
+    // VAR 64 (profiling): s_memtime stamps of wave 0 and wave 8, dumped over the start of the output at the end
+    unsigned long long ts[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ts[i] = 0;
+    auto stamp = [&](int i) __attribute__((always_inline)) { if (VAR & 64) ts[i] = __builtin_amdgcn_s_memtime(); };
+    auto dump = [&]() __attribute__((always_inline)) {
+        if ((VAR & 64) && p.dbg && lane == 0 && (wave == 0 || wave == 8)) {   // slot 0: staging wave 0, slot 1: matrix wave 8
+            unsigned long long *d = p.dbg + (blockIdx.x * 2 + (wave >> 3)) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = ts[i];
+        }
+    };
+    stamp(0);
 
     // ---- this workgroup's task list
     const int G = gridDim.x >> 3, strm = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -214,15 +229,27 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int xg = 4 * (ln & 15);
-        for (int row = wave * 4 + (ln >> 4); row < 16 * D; row += 64) {
+        constexpr int NR = (16 * D + 63) / 64;   // rows per lane group: 6 (the last one partial)
+        f4 vals[NR];
+        // all LDS reads first, then the arithmetic and the stores: one LDS latency per task instead of one per row
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = wave * 4 + (ln >> 4) + 64 * i;
+            const int pl = row / D;
+            const int rr = row < 16 * D ? row : 0;
+            vals[i] = *reinterpret_cast<const f4 *>(Os + rr * O_RS + ((xg + 4 * (4 * (pl & 3) + (pl >> 2))) & 63));
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = wave * 4 + (ln >> 4) + 64 * i;
             const int pl = row / D, ti = row - pl * D;
             const int ai = pl >> 2, bi = pl & 3;
             const int tj = 4 * tk.u + bi - ai;
             const int IL = 4 * tk.rg + ai;
-            if (tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
+            if (row >= 16 * D || tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
             const int y = 2 * IL + tk.py;
-            f4 val = *reinterpret_cast<const f4 *>(Os + row * O_RS + ((xg + 4 * (4 * bi + ai)) & 63));
-            if (VAR == 0) {
+            f4 val = vals[i];
+            if ((VAR & 127) == 0) {
                 const u4 bits = __builtin_bit_cast(u4, val);
                 const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
                                  ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
@@ -244,8 +271,11 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * p.slope;
             }
-            if (!(VAR & 4))
-                *reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = val;
+            if (!(VAR & 4)) {
+                f4 *dst = reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg);
+                if (VAR & 1024) *dst = val;
+                else __builtin_nontemporal_store(val, dst);   // written once, not read here: keep the inputs in L2 instead
+            }
         }
     };
 
@@ -321,42 +351,53 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         // Invariant at the top of a real task: its steps 0 and 1 are in flight in L0 and L1.  During step s buffer s&1 is
         // being read, register set (s+1)&1 holds step s+1 and set s&1 is free: it receives step s+2 of this task, or -- in
         // the last two steps -- step s+2-nsteps of the next real task.
+        // Channel order: every other task of a workgroup walks the channels backwards, so that it starts with the chunks the
+        // previous task (and the other workgroups of the XCD, which run in step) touched last -- those are still in L2.
+        auto chunk = [&](int it, int s) { return ((VAR & 512) || !(it & 1) ? s : nsteps - 1 - s) * CK; };
         LoadSet L0, L1;
         if (n_real > 0) {
             set_ctx(get_task(0), true);
-            issue_loads(L0, 0);
-            issue_loads(L1, CK);
+            issue_loads(L0, chunk(0, 0));
+            issue_loads(L1, chunk(0, 1));
         }
+        stamp(1);
         for (int it = 0; it < n_real; ++it) {
             const Task tk = get_task(it);
             const bool has_next = it + 1 < n_real;
             stage_write(L0, smem);
+            if (it < 2) stamp(2 + 6 * it);
             __syncthreads();
             for (int s = 0; s + 2 < nsteps; s += 2) {
-                issue_loads(L0, (s + 2) * CK);
+                issue_loads(L0, chunk(it, s + 2));
                 stage_write(L1, smem + BUF);
                 __syncthreads();
-                issue_loads(L1, (s + 3) * CK);
+                issue_loads(L1, chunk(it, s + 3));
                 stage_write(L0, smem);
                 __syncthreads();
             }
             // last two steps: the free register sets receive steps 0 and 1 of the next real task (after the last one the
             // offsets are out of range: the loads return zeros without touching memory)
             set_ctx(get_task(has_next ? it + 1 : it), has_next);
-            issue_loads(L0, 0);
+            issue_loads(L0, chunk(it + 1, 0));
             stage_write(L1, smem + BUF);
             __syncthreads();
-            issue_loads(L1, CK);
+            issue_loads(L1, chunk(it + 1, 1));
             __syncthreads();
+            if (it < 2) stamp(3 + 6 * it);
             __syncthreads();   // the epilogue image is complete
+            if (it < 2) stamp(4 + 6 * it);
             store_rows(tk);
+            if (it < 2) stamp(5 + 6 * it);
             __syncthreads();   // ... and has been read: the buffers are free
+            if (it < 2) stamp(6 + 6 * it);
         }
         for (int it = n_real; it < n_tasks; ++it) {   // zero-only tasks
             __syncthreads();
             store_rows(get_task(it));
             __syncthreads();
         }
+        stamp(15);
+        dump();
         return;
     }
 
@@ -365,6 +406,8 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     // receives, for j = 0..3, element (i & 3) of the chunk of block row i >> 2 -- i.e. pixel (row i>>2, column i&3) of the
     // block for 4 channels.  Lane group g reads channels 4g + j and, in a second read, 16 + 4g + j: the 8 k-slots of lane
     // group g of a 16x16x32 operand.
+    // the staging waves were dispatched first and would win every issue arbitration by age: give the matrix waves priority
+    if (!(VAR & 256)) __builtin_amdgcn_s_setprio(2);
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
     const int r_base = xpar * PARS + (4 * (lane >> 4) + ((lane & 15) >> 2)) * CHS + (lane & 3) * 8;
@@ -378,19 +421,20 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 
     f4 acc[NP];
     // One step: D = (in2 block) x (in1 block): rows = B pixels (bi = lane>>4, bj = register), columns = A pixels (lane & 15).
-    // B fragments are fetched one block ahead of their MFMAs.
     auto step = [&](auto role_c, const char *cur) {
         constexpr int R = decltype(role_c)::value;
         constexpr int NM = m_hi(R) - m_lo(R) + 1;
-        h8 ah[NAB], al[NAB];
+        // B fragments are fetched PF blocks ahead of their MFMAs
+        constexpr int PF = (VAR & 128) ? 2 : 1;
+        h8 ah[NAB], al[NAB], bh[PF + 1], bl[PF + 1];
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab) { ah[ab] = frag(cur, 0, 0, a_blk(R, ab)); al[ab] = frag(cur, 0, 1, a_blk(R, ab)); }
-        h8 bh[2], bl[2];
-        bh[0] = frag(cur, 1, 0, m_lo(R)); bl[0] = frag(cur, 1, 1, m_lo(R));
+#pragma unroll
+        for (int i = 0; i < PF; ++i) { bh[i] = frag(cur, 1, 0, m_lo(R) + i); bl[i] = frag(cur, 1, 1, m_lo(R) + i); }
         static_for<0, NM>([&](auto jc) {
             constexpr int jj = decltype(jc)::value, m = m_lo(R) + jj;
-            constexpr int cb = jj & 1, nb = cb ^ 1;
-            if constexpr (jj + 1 < NM) { bh[nb] = frag(cur, 1, 0, m + 1); bl[nb] = frag(cur, 1, 1, m + 1); }
+            constexpr int cb = jj % (PF + 1), nb = (jj + PF) % (PF + 1);
+            if constexpr (jj + PF < NM) { bh[nb] = frag(cur, 1, 0, m + PF); bl[nb] = frag(cur, 1, 1, m + PF); }
             if (VAR & 1) {
                 asm volatile("" ::"v"(bh[cb]), "v"(bl[cb]));
             } else {
@@ -450,7 +494,8 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         });
     };
 
-    auto epilogue = [&](const Task &tk) {
+    auto epilogue = [&](const Task &tk, int it) {
+        if (it < 2) stamp(3 + 6 * it);
         if (!(VAR & 32)) {
             switch (role) {
             case 0: scatter(std::integral_constant<int, 0>{}); break;
@@ -463,27 +508,36 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(acc[i]));
         }
         __syncthreads();
+        if (it < 2) stamp(4 + 6 * it);
         store_rows(tk);
+        if (it < 2) stamp(5 + 6 * it);
         __syncthreads();
+        if (it < 2) stamp(6 + 6 * it);
     };
     for (int it = 0; it < n_real; ++it) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
+        if (it < 2) stamp(2 + 6 * it);
         for (int s = 0; s < nsteps; s += 2) {
             step_dispatch(smem);
             __syncthreads();
             step_dispatch(smem + BUF);
             __syncthreads();
         }
-        epilogue(get_task(it));
+        epilogue(get_task(it), it);
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-    for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it));   // zero-only tasks
+    for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99);   // zero-only tasks
+    stamp(15);
+    dump();
 }
 
 } // namespace hf
+
+static unsigned long long *g_debug_buffer = nullptr;   // profiling only (fn2_debug.h)
+void corr_f16x2_set_debug_buffer(void *p) { g_debug_buffer = static_cast<unsigned long long *>(p); }
 
 bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2)
 {
@@ -502,6 +556,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     hf::Args a;
     a.in1 = in1; a.in2 = in2; a.out = out; a.out_bs = out_bs; a.slope = slope;
     a.B = B; a.C = C; a.H = H; a.W = W;
+    a.dbg = variant == 64 ? g_debug_buffer : nullptr;
     const int HL = H / 2, NRG = (HL + 3) / 4;
     if (2 * NRG * hf::NU > hf::MAX_TAB) return FN2_EUNSUPPORTED;
     // table of the (py, rg, u) combinations of one batch item: those whose B rows 4rg - 10 + 4u .. +3 meet [0, HL) first
@@ -529,7 +584,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     const int G = per_stream < 32 ? (int)per_stream : 32;
 #define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3(8u * G), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(63)
+        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536)
     default: return FN2_EINVAL;
     }
 #undef FN2_HF

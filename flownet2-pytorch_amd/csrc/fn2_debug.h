@@ -17,6 +17,8 @@ int fn2_debug_correlation_forward(const void *in1, const void *in2, void *out, i
 int fn2_debug_correlation_backward(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,
                                    int dtype, int B, int C, int H, int W, int pad_size, int kernel_size,
                                    int max_displacement, int stride1, int stride2, int variant, void *stream);
+/* device buffer (>= 64 KB) that forward variant 5064 dumps its s_memtime stamps into; NULL = none */
+void fn2_debug_set_buffer(void *device_ptr);
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ ap.add_argument("--check", action="store_true")
 ap.add_argument("--shape", default="8,256,48,64")
 ap.add_argument("--md", type=int, default=20)
 ap.add_argument("--bwd", default="")
+ap.add_argument("--batch", type=int, default=40)
 a = ap.parse_args()
 B, C, H, W = (int(v) for v in a.shape.split(","))
 dev = torch.device("cuda:0")
@@ -28,6 +29,9 @@ D = 2 * (a.md // 2) + 1
 out = torch.empty(B, D * D, H, W, device=dev)
 ref = None
 res = {}
+dbg = torch.zeros(256 * 2 * 16, dtype=torch.int64, device=dev)
+fn2_capi.lib().fn2_debug_set_buffer.restype = None
+fn2_capi.lib().fn2_debug_set_buffer(fn2_capi._p(dbg))
 for algo in (int(v) for v in a.algos.split(",")):
     try:
         for _ in range(3):
@@ -46,12 +50,37 @@ for algo in (int(v) for v in a.algos.split(",")):
     torch.cuda.synchronize()
     ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
     r = {"median_us": round(ts[len(ts) // 2], 2), "min_us": round(ts[0], 2)}
+    # back-to-back launches between one event pair: the per-launch time without the event pair's own ~6 us
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(a.batch):
+        fn2_capi.correlation_forward(in1, in2, a.md, 1, a.md, 1, 2, algo=algo, out=out)
+    e.record()
+    torch.cuda.synchronize()
+    r["b2b_us"] = round(s.elapsed_time(e) * 1e3 / a.batch, 2)
     if a.check and (algo in (2, 3, 4, 5000) or (100 <= algo < 1000 and (algo - 100) % 256 == 0) or (1000 <= algo < 5000 and algo % 10 == 0)):
         if ref is None:
             ref = fn2_capi.correlation_forward(in1, in2, a.md, 1, a.md, 1, 2, algo=1)
         r["max_abs_vs_direct"] = float((out - ref).abs().max())
     res[algo] = r
     print(algo, r, flush=True)
+    if algo == 5064:   # f16x2 timeline: stamps of wave 0 (matrix) and wave 8 (staging) of every workgroup
+        torch.cuda.synchronize()
+        st = dbg.cpu().view(256, 2, 16)
+        base = st[:, :, 0].min(dim=1, keepdim=True).values.unsqueeze(2)   # per workgroup (the XCDs have their own counters)
+        zero = st == 0
+        st = (st - base).double()
+        st[zero] = -1
+        t0 = 0
+        names = ["start", "loads issued", "t0 data ready", "t0 K done", "t0 image", "t0 stores issued", "t0 free",
+                 "-", "t1 data ready", "t1 K done", "t1 image", "t1 stores issued", "t1 free", "-", "-", "end"]
+        for role, rn in ((0, "matrix wave 0"), (1, "staging wave 8")):
+            print("  ", rn)
+            for i, nm in enumerate(names):
+                v = st[:, role, i]
+                v = v[v >= 0]
+                if len(v):
+                    print("     %-18s mean %8.0f  min %8.0f  max %8.0f   (n=%d)" % (nm, float((v - t0).mean()), float((v - t0).min()), float((v - t0).max()), len(v)))
     if algo == 3124:   # instrumented forward: s_memtime stamps of two workgroups (dispatch rounds 0 and 1 of one CU)
         torch.cuda.synchronize()
         st = out.view(-1)[:256].view(torch.int64).cpu().view(2, 8, 8)

@@ -12,7 +12,7 @@ i=0
 for G in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rm -rf $OUT/sq_$i
-  ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/$OUT/sq_$i -- python $R/scripts/corr_micro.py --algos 0 --bwd 0 --iters 3 > $R/$OUT/sq_$i.log 2>&1 ); echo "pass $i rc $?"
+  ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/$OUT/sq_$i -- python $R/scripts/corr_micro.py --algos ${SQ_ALGO:-0} ${SQ_BWD:---bwd 0} --iters 3 > $R/$OUT/sq_$i.log 2>&1 ); echo "pass $i rc $?"
 done
 python - <<'PY'
 import csv, glob, collections, json, os
@@ -23,7 +23,8 @@ for d in sorted(glob.glob("gpurun_out/sq_*/")):
     vals = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[-1])):
         kn = r["Kernel_Name"]
-        if "corr_fwd_mfma_bf16x3" in kn: k = "corr_fwd_mfma_bf16x3"
+        if "corr_fwd_f16x2" in kn: k = "corr_fwd_f16x2"
+        elif "corr_fwd_mfma_bf16x3" in kn: k = "corr_fwd_mfma_bf16x3"
         elif "corr_bwd_mfma_bf16x3" in kn: k = "corr_bwd_mfma_bf16x3"
         else: continue
         vals[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
