@@ -351,9 +351,10 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         // Invariant at the top of a real task: its steps 0 and 1 are in flight in L0 and L1.  During step s buffer s&1 is
         // being read, register set (s+1)&1 holds step s+1 and set s&1 is free: it receives step s+2 of this task, or -- in
         // the last two steps -- step s+2-nsteps of the next real task.
-        // Channel order: every other task of a workgroup walks the channels backwards, so that it starts with the chunks the
-        // previous task (and the other workgroups of the XCD, which run in step) touched last -- those are still in L2.
-        auto chunk = [&](int it, int s) { return ((VAR & 512) || !(it & 1) ? s : nsteps - 1 - s) * CK; };
+        // Channel order.  (Walking the channels backwards in every other task, to start with what is still in L2, measured no
+        // gain -- the fabric reads already equal the algorithmic bytes -- and would make the summation order depend on the
+        // task's place in the list; profiling switch 512 keeps the experiment.)
+        auto chunk = [&](int it, int s) { return ((VAR & 512) && (it & 1) ? nsteps - 1 - s : s) * CK; };
         LoadSet L0, L1;
         if (n_real > 0) {
             set_ctx(get_task(0), true);

@@ -454,6 +454,121 @@ def test_correlation_bf16x3_accuracy_vs_fp64(dev):
         assert e3 <= 3.0 * e32 + 1e-30, (scale, spread, e3, e32)
 
 
+F16X2_CASES = [   # (B, C, H, W): md = 20 (FlowNetC), W % 8 == 0 <= 64, C % 64 == 0
+    (1, 64, 16, 24), (2, 64, 12, 16), (1, 128, 48, 64), (1, 64, 6, 8), (3, 64, 10, 40), (1, 192, 22, 56), (9, 64, 20, 32),
+    (2, 64, 2, 8), (1, 64, 92, 64),
+]
+
+
+@pytest.mark.parametrize("case", F16X2_CASES)
+def test_correlation_f16x2_vs_oracle(dev, oracle, case):
+    """The f16x2 forward kernel (what FN2_CORR_AUTO picks for FlowNetC's cost volume) against the oracle: every output
+    element written, <= 1e-4 (the north star's bound), in fact fp32-rounding close; ragged lattices (H/2 not a multiple
+    of 4), partial widths and batch counts that do not divide the 8 streams."""
+    import fn2_capi
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    ad, bd = to_dev(a, dev), to_dev(b, dev)
+    out = torch.full((B, 441, H, W), float("nan"), device=dev)
+    fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2, out=out)
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all(), "f16x2 kernel left output elements unwritten"
+    items = range(B) if B * C * H * W <= 2 ** 21 else (0, B - 1)
+    for n in items:
+        ref = oracle.corr_fwd(a[n:n + 1], b[n:n + 1], 20, 1, 20, 1, 2)
+        assert max_abs(o[n:n + 1], ref) <= TOL
+        assert max_abs(o[n:n + 1], ref) <= 2e-6, "two-term f16 split should agree with the fp32 oracle to rounding"
+    auto = torch.full_like(out, float("nan"))
+    fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_AUTO, out=auto)
+    assert torch.equal(auto, out), "FN2_CORR_AUTO should select the f16x2 kernel for this configuration"
+    direct = fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    assert float((direct - out).abs().max()) <= 2e-6
+
+
+def test_correlation_f16x2_full_size_and_fused(dev, oracle):
+    """BASELINE configs[1] shape: against the direct kernel everywhere and the oracle on two batch items; the fused
+    LeakyReLU / channel-slice epilogue (fn2_correlation_forward_fused) is bit-identical to the unfused result."""
+    import fn2_capi
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(8, 256, 48, 64, generator=g)
+    b = torch.randn(8, 256, 48, 64, generator=g)
+    ad, bd = a.to(dev), b.to(dev)
+    out = fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    direct = fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    assert float((out - direct).abs().max()) <= 2e-6
+    for n in (0, 5):
+        ref = oracle.corr_fwd(a[n:n + 1].numpy(), b[n:n + 1].numpy(), 20, 1, 20, 1, 2)
+        assert max_abs(out[n:n + 1].cpu().numpy(), ref) <= 2e-6
+    buf = torch.full((8, 32 + 441 + 3, 48, 64), 7.0, device=dev)
+    fn2_capi.correlation_forward_fused(ad, bd, buf, 32, 0.1, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    assert (buf[:, :32] == 7.0).all() and (buf[:, 32 + 441:] == 7.0).all()
+    assert torch.equal(buf[:, 32:32 + 441], torch.nn.functional.leaky_relu(out, 0.1))
+
+
+def test_correlation_f16x2_out_of_range_operands(dev):
+    """Operands that do not fit an f16 (|x| >= 65520), infinities and NaNs: the affected outputs are recomputed in plain
+    fp32, so the result matches the fp32 kernels wherever those are finite and is non-finite exactly where they are."""
+    import fn2_capi
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(2, 64, 16, 24, generator=g)
+    b = torch.randn(2, 64, 16, 24, generator=g)
+    a[0, 3, 5, 7] = 1.0e5; a[0, 10, 2, 20] = -3.0e6; b[0, 7, 9, 9] = 7.0e4; b[0, 63, 15, 23] = -1.0e30
+    a[1, 0, 0, 0] = 65519.0; b[1, 1, 8, 12] = 65520.0; b[1, 5, 4, 4] = float("inf"); b[1, 9, 11, 3] = float("nan")
+    ad, bd = a.to(dev), b.to(dev)
+    out = fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    ref = fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT).double()
+    p2 = torch.nn.functional.pad(bd.double(), (20, 20, 20, 20))
+    scale = torch.cat([(ad.double().abs() * p2[:, :, 20 + 2 * tj:36 + 2 * tj, 20 + 2 * ti:44 + 2 * ti].abs()).mean(1, keepdim=True)
+                       for tj in range(-10, 11) for ti in range(-10, 11)], 1)   # sum |a b| / C: the natural error scale
+    fin = torch.isfinite(ref) & torch.isfinite(scale)
+    assert torch.equal(torch.isfinite(out), torch.isfinite(ref.float())), "non-finite outputs must coincide"
+    err = ((out.double() - ref).abs() / scale.clamp_min(1e-30))[fin]
+    assert float(err.max()) <= 1e-5, float(err.max())
+    assert int((~fin).sum()) > 0 and int(fin.sum()) > 0
+
+
+def test_correlation_f16x2_accuracy_vs_fp64(dev):
+    """Against an fp64 reference the f16x2 kernel is as accurate as the fp32 MFMA kernel for unit-scale and large inputs
+    and for wide dynamic range; for uniformly tiny inputs the 2^-25 absolute floor of the low term shows (documented in
+    include/flownet2_hip.h): still five orders below the north star's 1e-4."""
+    import fn2_capi
+    import torch.nn.functional as F
+    B, C, H, W = 2, 256, 48, 64
+    g = torch.Generator().manual_seed(22)
+
+    def ref64(x1, x2):
+        p2 = F.pad(x2.double(), (20, 20, 20, 20))
+        outs = [(x1.double() * p2[:, :, 20 + 2 * tj:20 + 2 * tj + H, 20 + 2 * ti:20 + 2 * ti + W]).mean(1, keepdim=True)
+                for tj in range(-10, 11) for ti in range(-10, 11)]
+        return torch.cat(outs, 1)
+
+    for scale, spread, factor in [(1.0, 0.0, 1.5), (100.0, 0.0, 1.5), (1.0, 3.0, 1.5), (1e-3, 0.0, 80.0)]:
+        x1 = (scale * torch.randn(B, C, H, W, generator=g) * torch.exp(spread * torch.randn(B, C, H, W, generator=g))).to(dev)
+        x2 = (scale * torch.randn(B, C, H, W, generator=g) * torch.exp(spread * torch.randn(B, C, H, W, generator=g))).to(dev)
+        r = ref64(x1, x2)
+        e32 = float((fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F32).double() - r).abs().max())
+        e16 = float((fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2).double() - r).abs().max())
+        assert e16 <= factor * e32 + 1e-30, (scale, spread, e16, e32)
+        assert e16 <= 1e-4 * max(1.0, float(r.abs().max())), (scale, spread, e16)
+
+
+def test_correlation_algo_selector_is_validated(dev):
+    """Unknown algo values are rejected (the profiling instantiations are only reachable through fn2_debug_*)."""
+    import ctypes
+    import fn2_capi
+    x = torch.randn(1, 64, 8, 8, device=dev)
+    out = torch.empty(1, 441, 8, 8, device=dev)
+    for algo in (5, 99, 100, 2100, 5001, -1, 0x40000000 | 5001):
+        rc = fn2_capi.lib().fn2_correlation_forward_ex(
+            ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0, 1, 64, 8, 8,
+            20, 1, 20, 1, 2, ctypes.c_int(algo), None)
+        assert rc == -1, (algo, rc)   # FN2_EINVAL
+    with pytest.raises(RuntimeError):   # f16x2 is forward only
+        fn2_capi.correlation_backward(x, x, torch.randn(1, 441, 8, 8, device=dev), 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+
+
 def test_correlation_full_size_properties(dev):
     """Size-independent properties at the BASELINE size: the all-ones pattern counts padding,
     the output is linear in in2, and batch items are independent."""
