@@ -141,7 +141,18 @@ static int corr_backward_impl(const void *in1, const void *in2, const void *grad
         return FN2_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!debug_variant && (algo < FN2_CORR_AUTO || algo > FN2_CORR_MFMA_F16X2)) return FN2_EINVAL;
-    if (!debug_variant && algo == FN2_CORR_MFMA_F16X2) return FN2_EUNSUPPORTED;   // forward only
+    // f16x2: one-time two-term f16 split, gathered G operand (correlation_f16x2_bwd.hip)
+    const bool f16x2_ok = corr_bwd_f16x2_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2) &&
+                          aligned(in1, 16) && aligned(in2, 16) && aligned(grad_out, 16) && aligned(grad_in1, 16) && aligned(grad_in2, 16);
+    if (debug_variant && algo >= 6000) {
+        if (!f16x2_ok) return FN2_EUNSUPPORTED;
+        return corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),
+                                   static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, algo - 6000, s);
+    }
+    if (!debug_variant && algo == FN2_CORR_MFMA_F16X2 && !f16x2_ok) return FN2_EUNSUPPORTED;
+    if (!debug_variant && (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok)))
+        return corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),
+                                   static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, 0, s);
     const bool mfma_ok = corr_bwd_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                       stride2) &&
                          aligned(in1, 8) && aligned(in2, 8) && aligned(grad_out, 8);

@@ -25,6 +25,9 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
                        int variant, hipStream_t s);
 
 void corr_f16x2_set_debug_buffer(void *p);
+bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
+int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
+                        int variant, hipStream_t s);
 
 bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,

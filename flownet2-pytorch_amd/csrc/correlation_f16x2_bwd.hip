@@ -1,0 +1,528 @@
+// correlation_f16x2_bwd.hip -- correlation backward (both input gradients) on the gfx950 f16 matrix cores, with the
+// operand handling of correlation_f16x2.hip: every fp32 value is split ONCE per staging into two f16 terms
+// (x = h + l, h = RNE_f16(x), l = RNE_f16(x - h)) and a product is ah*bh + ah*bl + al*bh in fp32 accumulators.
+//
+// Replaces reference kernels correlation_backward_input1 / correlation_backward_input2
+// (correlation_cuda_kernel.cu:150-241, :243-334; one launch per batch item each, :522-554) for FlowNetC's
+// configuration (kernel_size 1, stride1 1, stride2 2, pad == max_displacement == 20, fp32, maps up to 64 wide):
+//     gI1[n,c,p] = (1/C) * sum_d gO[n, tc(d), p     ] * in2[n,c, p + 2d]
+//     gI2[n,c,p] = (1/C) * sum_d gO[n, tc(d), p - 2d] * in1[n,c, p - 2d]          d in [-10,10]^2 (lattice units of 2 px)
+// Both are a banded contraction over the neighbours q of a "centre" pixel p on its parity lattice:
+//     g[c, p] = sum_q  X[c, q] * G[q, p]        X = in2, G[q,p] = gO[q - p][p]   (FLIP 0: the gO pixel is the centre)
+//                                               X = in1, G[q,p] = gO[p - q][q]   (FLIP 1: the gO pixel is the neighbour)
+// i.e. a matrix product with M = 16 channels, K = neighbour pixels (two 4x4 blocks = 32 per MFMA), N = the 16 centre
+// pixels of a 4x4 block.
+//
+// Task = (FLIP, n, y parity, row group rg of 4 centre lattice rows, group of 64 channels); the workgroup loops over the
+// 6 neighbour row blocks u itself (rows 4rg - 10 + 4u .. +3): the sum over neighbours stays in registers, no atomics,
+// deterministic.  Per u:
+//   G image   the 16 (centre row ai, neighbour row bi) combinations x 21 displacement columns x 64 pixels of gO that the
+//             pair (rg, u) touches -- the forward's output tile -- as f16 hi / lo planes [ai][bi][ti][x] in LDS (strides
+//             padded so that the gather below is conflict-free).  The G operand of (centre block a, neighbour block pair j)
+//             is a GATHER from it: lane (pixel, k group) picks 8 values with ds_read_u16 (one address register +
+//             immediates; values outside the 21-wide band come from a zero word); gathered once per u into registers
+//             and reused for the 4 channel tiles.
+//   X tile    4 neighbour rows x 64 pixels x 32 channels per chunk, the LDS image of the forward kernel (8-byte chunks of
+//             4 lattice columns, [term][parity][channel][column block][row]): the X operand of (channel tile, block pair)
+//             is two plain ds_read_b128 (hi, lo) -- the neighbour pixels of one channel are contiguous.
+// Waves are specialised as in the forward: waves 0-7 stage (buffer loads whose range check returns zeros outside the
+// image / the displacement range, split, LDS writes), waves 8-15 gather and run the MFMAs: wave w takes x parity w&1
+// and the centre column blocks of role w>>1 ({0,3},{1,2},{4,7},{5,6}: 6 (block, pair) products each) x 4 channel tiles.
+// Three barriers per u: [gather block 0's operands | write both X chunks] [MFMA block 0, gather block 1 | -] [MFMA block 1 | write G(u+1)].
+// Epilogue: accumulators -> LDS [channel][row][x] (16-byte slots rotated) -> rows of 256 B, scaled by 1/C; outputs that
+// came out non-finite (an operand did not fit an f16) are recomputed in plain fp32.
+#include <type_traits>
+
+#include "corr_params.h"
+
+namespace fn2 {
+namespace hb {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#define FN2_LDS(T) __attribute__((address_space(3))) T
+
+constexpr int DR = 10, D = 21, NU = 6;
+constexpr int CG = 64, NCT = CG / 16;             // channels per task, channel tiles of 16
+constexpr int CK = 32;                            // channels per X chunk (2 tiles)
+// X chunk image (bytes), as in correlation_f16x2.hip
+constexpr int CHS = 288, PARS = CK * CHS, XTERM = 2 * PARS, XBUF = 2 * XTERM;   // 9216, 18432, 36864
+// G image (bytes): [term][ai][bi][ti][64 x f16]; strides padded: bi stride = 64 mod 128, ai stride = 16 mod 128, so that the
+// 32 lanes of a gather (aj: 4 B apart, ai, bi parity) hit 32 distinct banks
+constexpr int G_TI = 128, G_BI = D * G_TI + 32, G_AI = 4 * G_BI + 16, GTERM = 4 * G_AI, GIMG = 2 * GTERM;   // 2720, 10896, 43584, 87168
+constexpr int X_OFS = GIMG, ZERO_OFS = X_OFS + 2 * XBUF, LDS_BYTES = ZERO_OFS + 64;                          // 87168, 160896, 160960
+constexpr int E_BYTES = CG * 4 * 64 * 4;          // epilogue image [64 channels][4 rows][64 x] floats, aliases the G image
+static_assert(E_BYTES <= GIMG && LDS_BYTES <= 163840, "LDS budget");
+static_assert(G_BI % 128 == 32 && (2 * G_BI) % 128 == 64 && G_AI % 128 == 16, "gather bank pattern");
+
+struct Args {
+    const float *nbr[2];   // [0] = in2 (neighbours for gradInput1), [1] = in1 (for gradInput2)
+    const float *gout;
+    float *gin[2];         // [0] = gradInput1, [1] = gradInput2
+    int B, C, H, W;        // H even, W % 8 == 0, W <= 64, C % 64 == 0
+    int NRG, NCGR;         // row groups per parity, channel groups
+    int nflip, flip0;      // 2: both gradients in this launch; 1: only flip0
+};
+
+// centre column blocks of a wave role and the block pairs (2j, 2j+1) they meet
+__host__ __device__ constexpr int a_blk(int role, int ab) { return role == 0 ? (ab ? 3 : 0) : role == 1 ? (ab ? 2 : 1) : role == 2 ? (ab ? 7 : 4) : (ab ? 6 : 5); }
+__host__ __device__ constexpr bool meets(int a, int j) { return 2 * j + 1 >= a - 3 && 2 * j <= a + 3; }   // j in 0..3
+__host__ __device__ constexpr int frag_idx(int role, int ab, int j)   // index among the role's (block, pair) products, or -1
+{
+    int idx = 0;
+    for (int b = 0; b < 2; ++b)
+        for (int jj = 0; jj < 4; ++jj) {
+            if (b == ab && jj == j) return meets(a_blk(role, ab), j) ? idx : -1;
+            if (meets(a_blk(role, b), jj)) ++idx;
+        }
+    return -1;
+}
+__host__ __device__ constexpr int frag_sub(int role, int ab, int j)   // index among the products of ONE centre block, or -1
+{
+    int idx = 0;
+    for (int jj = 0; jj < 4; ++jj) {
+        if (jj == j) return meets(a_blk(role, ab), j) ? idx : -1;
+        if (meets(a_blk(role, ab), jj)) ++idx;
+    }
+    return -1;
+}
+constexpr int NF = 4;   // block pairs a centre block can meet (2 .. 4)
+static_assert(frag_idx(0, 1, 3) == 5 && frag_idx(1, 1, 3) == -1 && frag_idx(1, 1, 2) == 5 && frag_idx(2, 1, 3) == 5 && frag_idx(3, 1, 3) == 5,
+              "6 products per role");
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+__device__ __forceinline__ float resid_lo(unsigned hp, float x)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(unsigned hp, float x)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_f16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a, b}, h2));
+}
+
+// one gradient element as a plain fp32 fma chain (cold path: outputs whose matrix-core result is non-finite)
+__device__ __forceinline__ float exact_grad(const Args &p, int flip, int n, int c, int y, int x)
+{
+    const long HW = (long)p.H * p.W;
+    const float *X = p.nbr[flip] + ((long)n * p.C + c) * HW;
+    const float *g = p.gout + (long)n * D * D * HW;
+    float s = 0.0f;
+    for (int tj = 0; tj < D; ++tj)
+        for (int ti = 0; ti < D; ++ti) {
+            const int sgn = flip ? -1 : 1;
+            const int yq = y + sgn * 2 * (tj - DR), xq = x + sgn * 2 * (ti - DR);   // the neighbour pixel
+            if (yq < 0 || yq >= p.H || xq < 0 || xq >= p.W) continue;
+            const long gp = flip ? (long)yq * p.W + xq : (long)y * p.W + x;          // the gO pixel
+            s = fmaf(g[(long)(tj * D + ti) * HW + gp], X[(long)yq * p.W + xq], s);
+        }
+    return s;
+}
+
+struct XSet { u4 v[2][2]; };       // one X chunk of one lane: [slot][half] x 16 B (8 pixels)
+constexpr int NGI = 11;            // G items (float4) per staging lane: 16 planes x 21 x 16 = 5376 = 10.5 x 512
+
+// VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no stores, 8 no gathers / operand reads,
+//      16 no split / LDS staging writes
+template <int VAR>
+__global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_stage = wave < 8;
+    const int w8 = wave & 7;
+    const int HL = p.H >> 1;
+    const long HW = (long)p.H * p.W;
+    const int per_fn = 2 * p.NRG * p.NCGR;                  // tasks per (flip, batch item)
+    const int ntasks = p.nflip * p.B * per_fn;
+    const float fC = (float)p.C;
+    const bool pow2 = (p.C & (p.C - 1)) == 0;
+    const float rC = 1.0f / fC;
+    if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero word(s) of the gathers
+
+    struct Task { int flip, n, py, rg, cg; };
+    auto get_task = [&](int t) -> Task {
+        Task k;
+        k.cg = t % p.NCGR; t /= p.NCGR;
+        k.rg = t % p.NRG; t /= p.NRG;
+        k.py = t & 1; t >>= 1;
+        k.n = t % p.B;
+        k.flip = p.nflip == 2 ? t / p.B : p.flip0;
+        k.cg = __builtin_amdgcn_readfirstlane(k.cg); k.rg = __builtin_amdgcn_readfirstlane(k.rg);
+        k.py = __builtin_amdgcn_readfirstlane(k.py); k.n = __builtin_amdgcn_readfirstlane(k.n);
+        k.flip = __builtin_amdgcn_readfirstlane(k.flip);
+        return k;
+    };
+
+    // ---- write-out of the epilogue image (all 16 waves): 256 rows (channel, centre row) of 64 floats, 4 rows per instruction
+    float *Es = reinterpret_cast<float *>(smem);
+    auto store_rows = [&](const Task &tk) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
+        const int xg = 4 * (ln & 15);
+        f4 vals[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 4 + (ln >> 4) + 64 * i;   // row = c * 4 + ai
+            const int c = row >> 2, ai = row & 3;
+            vals[i] = *reinterpret_cast<const f4 *>(Es + row * 64 + ((xg + 8 * ai + 32 * ((c >> 2) & 1)) & 63));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 4 + (ln >> 4) + 64 * i;
+            const int c = row >> 2, ai = row & 3;
+            const int IL = 4 * tk.rg + ai;
+            if (IL >= HL || xg >= p.W) continue;
+            const int y = 2 * IL + tk.py;
+            f4 val = vals[i];
+            if ((VAR & 31) == 0) {
+                const u4 bits = __builtin_bit_cast(u4, val);
+                const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
+                                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
+                if (bad) {
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e) {
+                        const float ex = exact_grad(p, tk.flip, tk.n, tk.cg * CG + c, y, xg + e);
+                        const unsigned be = e == 0 ? bits[0] : e == 1 ? bits[1] : e == 2 ? bits[2] : bits[3];
+                        if ((be & 0x7f800000u) == 0x7f800000u) {
+                            val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
+                            val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
+                        }
+                    }
+                }
+            }
+            if (pow2) val *= rC;
+            else { val[0] /= fC; val[1] /= fC; val[2] /= fC; val[3] /= fC; }
+            if (!(VAR & 4))
+                *reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg) = val;
+        }
+    };
+
+    if (is_stage) {
+        // ================= staging waves =================
+        // G items: 16 B of gO each.  Item k (0 .. 10) of a lane: plane = 2 w8 + (lane >> 5), ti = 2k + ((lane >> 4) & 1),
+        // x4 = lane & 15 -- LDS offset and gO offset are linear in k (immediates / scalar offsets), validity does not
+        // depend on k except for ti = 21 (k = 10, odd half)
+        // X items (as the forward's tiles): slot k covers channels 16k .. 16k+15 of the chunk
+        const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
+        const int s_row = (lane >> 2) & 3;
+        const int s_ch = 2 * w8 + (lane >> 5);
+        const int s_x = 8 * s_piece;
+        const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;
+        const unsigned xbytes = (unsigned)(p.C * HW * 4), gbytes = (unsigned)(D * D * HW * 4);
+
+        for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
+            const Task tk = get_task(t);
+            const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int g_plane = 2 * w8 + (ln >> 5), g_ai = g_plane >> 2, g_bi = g_plane & 3;
+            const int g_tih = (ln >> 4) & 1, g_x4 = ln & 15;
+            const int g_ofs = g_ai * G_AI + g_bi * G_BI + g_tih * G_TI + g_x4 * 8;      // + k * 2 * G_TI
+            // FLIP 0: tj = 4u + bi - ai, gO row = centre row ai.   FLIP 1: tj = 20 - 4u - bi + ai, gO row = neighbour row bi
+            const int g_tj0 = tk.flip ? 20 - g_bi + g_ai : g_bi - g_ai;                  // tj at u = 0; +-4 per u
+            const int g_il0 = tk.flip ? 4 * tk.rg - DR + g_bi : 4 * tk.rg + g_ai;         // gO lattice row at u = 0; +4 per u for FLIP 1
+            const int g_base = ((g_tj0 * D + g_tih) * p.H + 2 * g_il0 + tk.py) * p.W + 4 * g_x4;   // element offset at u = 0, k = 0
+            const int g_du = tk.flip ? (-4 * D * p.H + 8) * p.W : 4 * D * p.H * p.W;      // element offset step per u
+            const int g_dk = 2 * p.H * p.W;                                               // ... per k (two ti planes)
+            u4 gv[NGI];
+            auto g_issue = [&](int u) {
+                const int tj = tk.flip ? g_tj0 - 4 * u : g_tj0 + 4 * u;
+                const int il = tk.flip ? g_il0 + 4 * u : g_il0;
+                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL && 4 * g_x4 < p.W;
+                const unsigned vo = ok ? (unsigned)((g_base + u * g_du) * 4) : 0x80000000u;
+                const unsigned vo_last = g_tih ? 0x80000000u : vo;                        // k = 10: ti = 20 / 21
+#pragma unroll
+                for (int k = 0; k < NGI; ++k) {
+                    if (VAR & 2) gv[k] = (u4)(0x3c000000u + lane);
+                    else gv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)(k == NGI - 1 ? vo_last : vo), k * g_dk * 4, 0);
+                }
+            };
+            auto g_write = [&]() {
+#pragma unroll
+                for (int k = 0; k < NGI; ++k) {
+                    if (VAR & 16) { asm volatile("" ::"v"(gv[k])); continue; }
+                    const f4 x = __builtin_bit_cast(f4, gv[k]);
+                    const unsigned h01 = pk_f16(x[0], x[1]), h23 = pk_f16(x[2], x[3]);
+                    const unsigned l01 = pk_f16(resid_lo(h01, x[0]), resid_hi(h01, x[1]));
+                    const unsigned l23 = pk_f16(resid_lo(h23, x[2]), resid_hi(h23, x[3]));
+                    if (k < NGI - 1 || !g_tih) {
+                        *(FN2_LDS(u2) *)(smem + g_ofs + k * 2 * G_TI) = (u2){h01, h23};
+                        *(FN2_LDS(u2) *)(smem + g_ofs + k * 2 * G_TI + GTERM) = (u2){l01, l23};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // X chunk (u, ch): neighbour rows 4rg - 10 + 4u .. +3, channels cg*64 + 32*ch .. +31
+            auto x_issue = [&](XSet &L, int u, int ch) {
+                const int il = 4 * tk.rg - DR + 4 * u + s_row;
+                const bool ok = il >= 0 && il < HL && s_x < p.W;
+                const unsigned vo = ok ? (unsigned)((s_ch * HW + (long)(2 * il + tk.py) * p.W + s_x) * 4) : 0x80000000u;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int soff = (int)((tk.cg * CG + ch * CK + 16 * k) * HW * 4);
+                    if (VAR & 2) { L.v[k][0] = (u4)(0x3c000000u + lane); L.v[k][1] = L.v[k][0]; continue; }
+                    L.v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, soff, 0);
+                    L.v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(vo + 16), soff, 0);
+                }
+            };
+            auto x_write = [&](const XSet &L, char *buf) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); continue; }
+                    const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]);
+                    char *dst = buf + w_ofs + k * 16 * CHS;
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
+                        const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
+                        const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
+                        const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+                        *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
+                        *(FN2_LDS(u2) *)(dst + XTERM + par * PARS) = (u2){l01, l23};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+
+            // prologue: G(0) into LDS, both X chunks of u = 0 and G(1) in flight
+            XSet X0, X1;
+            g_issue(0);
+            x_issue(X0, 0, 0);
+            x_issue(X1, 0, 1);
+            g_write();
+            g_issue(1);
+            __syncthreads();                                   // (A) G(0) complete
+            for (int u = 0; u < NU; ++u) {
+                // phase 1 (the matrix waves gather the first centre block's operands): both X chunks of u
+                x_write(X0, smem + X_OFS);
+                x_write(X1, smem + X_OFS + XBUF);
+                if (u + 1 < NU) { x_issue(X0, u + 1, 0); x_issue(X1, u + 1, 1); }
+                __syncthreads();                               // (B)
+                // phase 2 (MFMAs of the first centre block, gather of the second): nothing to write, the image is in use
+                __syncthreads();                               // (C) the G image is free
+                // phase 3 (MFMAs of the second centre block): G(u+1)
+                if (u + 1 < NU) g_write();
+                if (u + 2 < NU) g_issue(u + 2);
+                __syncthreads();                               // (A')
+            }
+            __syncthreads();                                   // epilogue image complete
+            store_rows(tk);
+            __syncthreads();                                   // image read: LDS free for the next task
+        }
+        return;
+    }
+
+    // ================= matrix-core waves =================
+    __builtin_amdgcn_s_setprio(2);
+    const int xpar = w8 & 1;
+    const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
+
+    auto run_task = [&](const Task &tk, auto flipc) {
+        constexpr int FLIP = decltype(flipc)::value;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int f_i = ln & 15, f_g = ln >> 4;                 // pixel / channel index, k group
+        const int f_ai = f_i >> 2, f_aj = f_i & 3;
+        // X operand base: lane = (channel i, k group g): block 2j + (g>>1), rows 2(g&1), 2(g&1)+1 -> 16 contiguous bytes
+        const int xb = xpar * PARS + f_i * CHS + (f_g >> 1) * 32 + (f_g & 1) * 16;
+
+        f4 acc[2][NCT];
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        h8 gh[NF], gl[NF];   // the operands of ONE centre block at a time
+
+        // Gather of the G operands.  Slot s of k group g = neighbour (block m = 2j + blk, row bi = 2gg + (s>>2), column bj = s&3)
+        // with blk = g>>1, gg = g&1, dm = m - a:
+        //   FLIP 0: ti = 4 dm + bj - aj + 10, x = 8a + 2aj + par      FLIP 1: ti = 10 - 4 dm - bj + aj, x = 8m + 2bj + par
+        // byte offset = ai G_AI + bi G_BI + ti 128 + 2x = lane part + slot part + (a, j) part; the lane part is recomputed in
+        // every call from an opaque copy of the lane id (hoisted out of the u loop it would be 48 live addresses).
+        auto gather = [&](auto role_c, auto abc) {
+            constexpr int R = decltype(role_c)::value;
+            constexpr int ab = decltype(abc)::value;
+            constexpr int a = a_blk(R, ab);
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = l2 >> 5, gg = (l2 >> 4) & 1;
+            const int lbase = FLIP ? ai * G_AI + 2 * gg * G_BI + (DR - 4 * blk + aj) * G_TI - 3 * (G_TI - 4) + 16 * blk + 2 * xpar
+                                   : ai * G_AI + 2 * gg * G_BI + (DR + 4 * blk - aj) * G_TI + 4 * aj + 2 * xpar;
+            const int t0 = FLIP ? DR - 4 * blk + aj : DR + 4 * blk - aj;        // ti = t0 -+ 4 (2j - a) -+ bj
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int fi = frag_sub(R, ab, j);
+                if constexpr (fi >= 0) {
+                    constexpr int dj = 2 * j - a;                             // dm = dj + blk
+                    constexpr int pconst = FLIP ? -4 * dj * G_TI + 32 * j : 4 * dj * G_TI + 16 * a;
+                    constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
+                    const int fbase = lbase + pconst;
+                    const int tb = FLIP ? t0 - 4 * dj : t0 + 4 * dj;          // ti of bj = 0
+                    s8 vh, vl;
+                    static_for<0, 8>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        constexpr int bjs = s & 3, bis = s >> 2;
+                        constexpr int sconst = FLIP ? bis * G_BI + (3 - bjs) * (G_TI - 4) : bis * G_BI + bjs * G_TI;
+                        int ofs = fbase + sconst, ofl = ofs + GTERM;
+                        if constexpr (check) {
+                            const int ti = FLIP ? tb - bjs : tb + bjs;
+                            const bool ok = ti >= 0 && ti < D;
+                            ofs = ok ? ofs : ZERO_OFS;
+                            ofl = ok ? ofl : ZERO_OFS;
+                        }
+                        if (VAR & 8) { vh[s] = (short)0x3c00; vl[s] = 0; }
+                        else {
+                            vh[s] = *reinterpret_cast<const short *>(smem + ofs);
+                            vl[s] = *reinterpret_cast<const short *>(smem + ofl);
+                        }
+                    });
+                    gh[fi] = __builtin_bit_cast(h8, vh);
+                    gl[fi] = __builtin_bit_cast(h8, vl);
+                    __builtin_amdgcn_sched_barrier(0);   // one operand at a time: 16 loads in flight
+                }
+            });
+        };
+        // MFMAs of one centre block over both X chunks (4 channel tiles): D[channel][pixel] += X[channel][q] * G[q][pixel]
+        auto mma = [&](auto role_c, auto abc) {
+            constexpr int R = decltype(role_c)::value;
+            constexpr int ab = decltype(abc)::value;
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int fi = frag_sub(R, ab, j);
+                if constexpr (fi >= 0) {
+                    static_for<0, NCT>([&](auto ctc) {
+                        constexpr int ct = decltype(ctc)::value;
+                        const char *buf = smem + X_OFS + (ct >> 1) * XBUF + (ct & 1) * 16 * CHS;
+                        h8 xh, xl;
+                        if (VAR & 8) { xh = (h8)((_Float16)1.0f); xl = xh; }
+                        else {
+                            xh = *reinterpret_cast<const h8 *>(buf + xb + j * 64);
+                            xl = *reinterpret_cast<const h8 *>(buf + xb + j * 64 + XTERM);
+                        }
+                        if (VAR & 1) { asm volatile("" ::"v"(xh), "v"(xl)); return; }
+                        acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, gh[fi], acc[ab][ct], 0, 0, 0);
+                        acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, gl[fi], acc[ab][ct], 0, 0, 0);
+                        acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, gh[fi], acc[ab][ct], 0, 0, 0);
+                    });
+                }
+            });
+        };
+        auto gather_d = [&](auto abc) {
+            switch (role) {
+            case 0: gather(std::integral_constant<int, 0>{}, abc); break;
+            case 1: gather(std::integral_constant<int, 1>{}, abc); break;
+            case 2: gather(std::integral_constant<int, 2>{}, abc); break;
+            default: gather(std::integral_constant<int, 3>{}, abc); break;
+            }
+        };
+        auto mma_d = [&](auto abc) {
+            switch (role) {
+            case 0: mma(std::integral_constant<int, 0>{}, abc); break;
+            case 1: mma(std::integral_constant<int, 1>{}, abc); break;
+            case 2: mma(std::integral_constant<int, 2>{}, abc); break;
+            default: mma(std::integral_constant<int, 3>{}, abc); break;
+            }
+        };
+
+        __syncthreads();                                       // (A) G(0) complete
+        for (int u = 0; u < NU; ++u) {
+            gather_d(std::integral_constant<int, 0>{});        // phase 1: operands of the first centre block
+            __syncthreads();                                   // (B) both X chunks of u complete
+            mma_d(std::integral_constant<int, 0>{});           // phase 2
+            gather_d(std::integral_constant<int, 1>{});
+            __syncthreads();                                   // (C) the G image is free
+            mma_d(std::integral_constant<int, 1>{});           // phase 3
+            __syncthreads();                                   // (A') the X buffers are free; G(u+1) complete
+        }
+
+        // epilogue: D[row = channel 4q + r][col = pixel i] -> Es[c][ai][x], 16-byte slots rotated by 8 ai + 32 ((c>>2)&1)
+        auto scatter = [&](auto role_c) {
+            constexpr int R = decltype(role_c)::value;
+            static_for<0, 2>([&](auto abc) {
+                constexpr int ab = decltype(abc)::value;
+                constexpr int a = a_blk(R, ab);
+                const int x = 8 * a + 2 * f_aj + xpar;
+                static_for<0, NCT>([&](auto ctc) {
+                    constexpr int ct = decltype(ctc)::value;
+                    static_for<0, 4>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        const int c = 16 * ct + 4 * f_g + r;
+                        Es[(c * 4 + f_ai) * 64 + ((x + 8 * f_ai + 32 * (f_g & 1)) & 63)] = acc[ab][ct][r];
+                    });
+                });
+            });
+        };
+        switch (role) {
+        case 0: scatter(std::integral_constant<int, 0>{}); break;
+        case 1: scatter(std::integral_constant<int, 1>{}); break;
+        case 2: scatter(std::integral_constant<int, 2>{}); break;
+        default: scatter(std::integral_constant<int, 3>{}); break;
+        }
+        __syncthreads();
+        store_rows(tk);
+        __syncthreads();
+    };
+    for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
+        const Task tk = get_task(t);
+        if (tk.flip) run_task(tk, std::integral_constant<int, 1>{});
+        else run_task(tk, std::integral_constant<int, 0>{});
+    }
+}
+
+} // namespace hb
+
+bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2)
+{
+    if (dtype != FN2_F32) return false;
+    if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md != 2 * hb::DR) return false;
+    if (C % hb::CG != 0 || C < hb::CG || (H & 1) || (W % 8) != 0 || W > 64) return false;
+    if ((long)C * H * W * 4 >= 0x7fffffffL || (long)hb::D * hb::D * H * W * 4 >= 0x7fffffffL) return false;
+    return true;
+}
+
+// which: 0 = both gradients, 1 = gradInput1 only, 2 = gradInput2 only; variant: profiling switches (fn2_debug.h)
+int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
+                        int variant, hipStream_t s)
+{
+    if (!aligned(in1, 16) || !aligned(in2, 16) || !aligned(gout, 16) || !aligned(g1, 16) || !aligned(g2, 16)) return FN2_EALIGN;
+    hb::Args a;
+    a.nbr[0] = in2; a.nbr[1] = in1; a.gout = gout; a.gin[0] = g1; a.gin[1] = g2;
+    a.B = B; a.C = C; a.H = H; a.W = W;
+    a.NRG = (H / 2 + 3) / 4; a.NCGR = C / hb::CG;
+    a.nflip = 2; a.flip0 = 0;
+    const long ntasks = 2L * B * 2 * a.NRG * a.NCGR;
+    if (ntasks == 0) return FN2_OK;
+    if (ntasks > 0x3fffffffL) return FN2_EINVAL;
+    const unsigned grid = ntasks < 256 ? (unsigned)ntasks : 256u;   // persistent: one workgroup per CU
+#define FN2_HB(V) case V: hipLaunchKernelGGL((hb::corr_bwd_f16x2<V>), dim3(grid), dim3(1024), 0, s, a); return launch_status();
+    switch (variant) {
+        FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31)
+    default: return FN2_EINVAL;
+    }
+#undef FN2_HB
+}
+
+} // namespace fn2

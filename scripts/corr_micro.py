@@ -109,7 +109,7 @@ if a.bwd:
         torch.cuda.synchronize()
         ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
         r = {"median_us": round(ts[len(ts) // 2], 2), "min_us": round(ts[0], 2)}
-        if algo >= 100 and (algo - 140) >= 0 and ((algo - 140) & 128):
+        if 100 <= algo < 6000 and (algo - 140) >= 0 and ((algo - 140) & 128):
             # instrumented instantiation: s_memtime stamps of one phase of each wave of one workgroup (100 MHz ticks)
             torch.cuda.synchronize()
             st = g1.view(-1)[:128].view(torch.int64).cpu().view(8, 8)

@@ -10,3 +10,5 @@ fi
 timeout 300 python scripts/corr_micro.py --check --algos ${ALGOS:-4,3,5001,5002,5004,5008,5016,5032,5006,5024,5025,5038,5063} > $OUT/f16x2_micro.log 2>&1; tail -16 $OUT/f16x2_micro.log | head -15
 [ "${ACC:-0}" = 1 ] && { timeout 300 python scripts/corr_accuracy.py --algos 2,3,4 > $OUT/f16x2_accuracy.log 2>&1; tail -24 $OUT/f16x2_accuracy.log; }
 true
+[ -n "${BWD:-}" ] && { timeout 300 python scripts/corr_micro.py --check --algos 4 --bwd $BWD > $OUT/f16x2_bwd_micro.log 2>&1; grep -v "^{" $OUT/f16x2_bwd_micro.log | tail -12; }
+true
