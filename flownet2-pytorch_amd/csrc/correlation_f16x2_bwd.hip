@@ -413,20 +413,29 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
                 constexpr int j = decltype(jc)::value;
                 constexpr int fi = frag_sub(R, ab, j);
                 if constexpr (fi >= 0) {
-                    static_for<0, NCT>([&](auto ctc) {
-                        constexpr int ct = decltype(ctc)::value;
+                    // the X operands of the 4 channel tiles first, then the three products tile by tile: consecutive MFMAs
+                    // work on different accumulators
+                    h8 xh[NCT], xl[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
                         const char *buf = smem + X_OFS + (ct >> 1) * XBUF + (ct & 1) * 16 * CHS;
-                        h8 xh, xl;
-                        if (VAR & 8) { xh = (h8)((_Float16)1.0f); xl = xh; }
+                        if (VAR & 8) { xh[ct] = (h8)((_Float16)1.0f); xl[ct] = xh[ct]; }
                         else {
-                            xh = *reinterpret_cast<const h8 *>(buf + xb + j * 64);
-                            xl = *reinterpret_cast<const h8 *>(buf + xb + j * 64 + XTERM);
+                            xh[ct] = *reinterpret_cast<const h8 *>(buf + xb + j * 64);
+                            xl[ct] = *reinterpret_cast<const h8 *>(buf + xb + j * 64 + XTERM);
                         }
-                        if (VAR & 1) { asm volatile("" ::"v"(xh), "v"(xl)); return; }
-                        acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, gh[fi], acc[ab][ct], 0, 0, 0);
-                        acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, gl[fi], acc[ab][ct], 0, 0, 0);
-                        acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, gh[fi], acc[ab][ct], 0, 0, 0);
-                    });
+                    }
+                    if (VAR & 1) {
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) asm volatile("" ::"v"(xh[ct]), "v"(xl[ct]));
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ct], gh[fi], acc[ab][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ct], gl[fi], acc[ab][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[ct], gh[fi], acc[ab][ct], 0, 0, 0);
+                    }
                 }
             });
         };

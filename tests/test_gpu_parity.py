@@ -358,6 +358,60 @@ def test_correlation_bf16x3_backward_vs_oracle(dev, oracle, case):
         assert e1 <= 5e-6 * scale and e2 <= 5e-6 * scale, (algo, e1, e2)
 
 
+BWD_F16X2_CASES = [  # B, C, H, W: the f16x2 backward kernel's domain (md = 20, C % 64 == 0, W % 8 == 0 <= 64)
+    (1, 64, 6, 8), (2, 64, 8, 8), (1, 64, 16, 24), (1, 64, 10, 40), (1, 128, 22, 56), (1, 64, 46, 64), (3, 64, 2, 16), (1, 192, 12, 32),
+]
+
+
+@pytest.mark.parametrize("case", BWD_F16X2_CASES)
+def test_correlation_f16x2_backward_vs_oracle(dev, oracle, case):
+    """The f16x2 backward kernel (what FN2_CORR_AUTO picks for FlowNetC's cost volume) against the oracle; every gradient
+    element written; ragged lattices and partial widths."""
+    import fn2_capi
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W + 3)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    go = rng.standard_normal((B, 441, H, W)).astype(np.float32)
+    ad, bd, gd = to_dev(a, dev), to_dev(b, dev), to_dev(go, dev)
+    r1, r2 = oracle.corr_bwd(a, b, go, 20, 1, 20, 1, 2)
+    scale = max(1.0, float(np.abs(r1).max()))
+    res = {}
+    for algo in (fn2_capi.FN2_CORR_MFMA_F16X2, fn2_capi.FN2_CORR_AUTO):
+        g1 = torch.full((B, C, H, W), float("nan"), device=dev)
+        g2 = torch.full((B, C, H, W), float("nan"), device=dev)
+        fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=algo, out=(g1, g2))
+        n1, n2 = g1.cpu().numpy(), g2.cpu().numpy()
+        assert np.isfinite(n1).all() and np.isfinite(n2).all(), "unwritten gradient elements"
+        e1, e2 = max_abs(n1, r1), max_abs(n2, r2)
+        assert e1 <= TOL and e2 <= TOL, (algo, e1, e2)
+        assert e1 <= 5e-6 * scale and e2 <= 5e-6 * scale, (algo, e1, e2)
+        res[algo] = (g1, g2)
+    assert torch.equal(res[fn2_capi.FN2_CORR_AUTO][0], res[fn2_capi.FN2_CORR_MFMA_F16X2][0]), "AUTO should select f16x2 here"
+    assert torch.equal(res[fn2_capi.FN2_CORR_AUTO][1], res[fn2_capi.FN2_CORR_MFMA_F16X2][1])
+
+
+def test_correlation_f16x2_backward_out_of_range_operands(dev):
+    """gradOutput / input values that do not fit an f16, infinities and NaNs: the affected gradient elements are
+    recomputed in plain fp32 -- same finite/non-finite pattern as the general kernel, same values where finite."""
+    import fn2_capi
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(2, 64, 16, 24, generator=g)
+    b = torch.randn(2, 64, 16, 24, generator=g)
+    go = torch.randn(2, 441, 16, 24, generator=g)
+    a[0, 3, 5, 7] = 1.0e5; b[0, 7, 9, 9] = -7.0e4; go[0, 200, 4, 4] = 3.0e6; go[0, 17, 12, 20] = -65520.0
+    a[1, 5, 4, 4] = float("inf"); b[1, 9, 11, 3] = float("nan"); go[1, 300, 8, 8] = float("inf")
+    ad, bd, gd = a.to(dev), b.to(dev), go.to(dev)
+    g1, g2 = fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    r1, r2 = fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    for got, ref in ((g1, r1), (g2, r2)):
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(got), fin), "non-finite gradient elements must coincide"
+        assert int(fin.sum()) > 0 and int((~fin).sum()) > 0
+        err = (got[fin].double() - ref[fin].double()).abs()
+        assert float(err.max()) <= 2e-6 * float(ref[fin].abs().max()), float(err.max())
+
+
 def test_correlation_bf16x3_backward_rejects_outside_domain(dev):
     import fn2_capi
     x = torch.randn(1, 32, 8, 8, device=dev)          # C % 64 != 0
@@ -392,12 +446,13 @@ def test_correlation_backward_accuracy_vs_fp64(dev):
     loss.backward()
     r1, r2 = a64.grad, b64.grad
     errs = {}
-    for name, algo in (("f32", fn2_capi.FN2_CORR_MFMA_F32), ("bf16x3", fn2_capi.FN2_CORR_MFMA_BF16X3)):
+    for name, algo in (("f32", fn2_capi.FN2_CORR_MFMA_F32), ("bf16x3", fn2_capi.FN2_CORR_MFMA_BF16X3),
+                       ("f16x2", fn2_capi.FN2_CORR_MFMA_F16X2)):
         g1, g2 = fn2_capi.correlation_backward(x1, x2, go, 20, 1, 20, 1, 2, algo=algo)
         errs[name] = max(float((g1.double() - r1).abs().max()), float((g2.double() - r2).abs().max()))
     tol = 3e-6 * float(r1.abs().max())
-    assert errs["f32"] <= tol and errs["bf16x3"] <= tol, (errs, tol)
-    assert errs["bf16x3"] <= 3.0 * errs["f32"], errs
+    assert errs["f32"] <= tol and errs["bf16x3"] <= tol and errs["f16x2"] <= tol, (errs, tol)
+    assert errs["bf16x3"] <= 3.0 * errs["f32"] and errs["f16x2"] <= 3.0 * errs["f32"], errs
     # linearity in gradOutput, batch independence (automatic path)
     go2 = torch.randn(B, 441, H, W, generator=g).to(dev)
     s1, s2 = fn2_capi.correlation_backward(x1, x2, go + go2, 20, 1, 20, 1, 2)
@@ -565,8 +620,9 @@ def test_correlation_algo_selector_is_validated(dev):
             ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0, 1, 64, 8, 8,
             20, 1, 20, 1, 2, ctypes.c_int(algo), None)
         assert rc == -1, (algo, rc)   # FN2_EINVAL
-    with pytest.raises(RuntimeError):   # f16x2 is forward only
-        fn2_capi.correlation_backward(x, x, torch.randn(1, 441, 8, 8, device=dev), 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    with pytest.raises(RuntimeError):   # outside the f16x2 domain (C % 64 != 0)
+        y = torch.randn(1, 32, 8, 8, device=dev)
+        fn2_capi.correlation_backward(y, y, torch.randn(1, 441, 8, 8, device=dev), 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
 
 
 def test_correlation_full_size_properties(dev):
