@@ -123,6 +123,30 @@ class HotPath:
         timed("resample_bwd", res_bwd)
 
 
+    def module_steps(self, steps):
+        """`steps` fwd+bwd passes through the nn.Module wrappers and autograd (wall clock, synchronised)."""
+        from networks.channelnorm_package.channelnorm import ChannelNorm
+        from networks.correlation_package.correlation import Correlation
+        from networks.resample2d_package.resample2d import Resample2d
+        corr, warp, norm = Correlation(*self.cparams), Resample2d(), ChannelNorm()
+        a, b = self.in1.clone().requires_grad_(True), self.in2.clone().requires_grad_(True)
+        img1, flow = self.img.clone().requires_grad_(True), self.flow.clone().requires_grad_(True)
+        img0 = self.gwarp
+
+        def one():
+            a.grad = b.grad = img1.grad = flow.grad = None
+            corr(a, b).backward(self.gcorr)
+            norm(img0 - warp(img1, flow)).backward(self.gnorm)
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
 def cpu_baseline(max_seconds=30.0):
     """Oracle (a C restatement of the reference kernels, OpenMP over the host cores) on a bounded
     sample: whole steps of the same workload (batch 8), repeated while the time budget allows."""
@@ -247,6 +271,10 @@ def main():
     torch.cuda.synchronize()
     eager_elapsed = time.perf_counter() - t1
 
+    # The same step through the shipped autograd wrappers (Correlation / Resample2d / ChannelNorm modules, with the
+    # difference op of models.py:135 between warp and norm): what a training script pays, allocations included.
+    mod_elapsed = hp.module_steps(args.steps)
+
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
         if roof_events.get("corr_fwd"):   # roofline: the durations recorded inside the timed region
@@ -293,6 +321,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "launch": "hipGraph replay of the step" if graph is not None else "eager launches",
             "ms_per_step_eager_with_events": round(eager_elapsed / args.steps * 1e3, 4),
+            "ms_per_step_autograd_modules": round(mod_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -309,7 +338,7 @@ def main():
                 "image_pairs_per_s_per_gpu": round(CORR["B"] / ((kernels["corr_fwd"]["ms"] + kernels["corr_bwd"]["ms"]) * 1e-3), 1),
             },
             "roofline": {
-                "kernel": "correlation forward (corr_fwd_mfma_bf16x3)",
+                "kernel": "correlation forward (corr_fwd_f16x2)",
                 "bound": "hbm",
                 "achieved": cf["achieved_GBps"],
                 "peak": HBM_PEAK_GBS,
@@ -322,17 +351,17 @@ def main():
                                                                   # durations are shorter than launch_ms by about this much
                 "algorithmic_bytes": cf["algorithmic_bytes"],
             },
-            # the same kernel against the matrix-core roof: it issues 6 bf16 MFMAs (exact 3-term operand split) per 16x16x32
-            # block product over the 6x6 neighbour blocks of every 4x4 pixel block (76.6 % of them inside the 21x21 band)
+            # the same kernel against the matrix-core roof: 3 f16 MFMAs (two-term operand split) per 16x16x32 block product;
+            # 480 tasks with neighbour rows inside the image x 8 channel steps x 8 matrix waves x 33 MFMAs x 16384 FLOP
             "roofline_mfma": (lambda mfma_flop: {
-                "kernel": "correlation forward (corr_fwd_mfma_bf16x3)", "bound": "mfma",
+                "kernel": "correlation forward (corr_fwd_f16x2)", "bound": "mfma",
                 "achieved": round(mfma_flop / (cf["ms"] * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(mfma_flop / (cf["ms"] * 1e-3) / 1e12 / 2500.0, 4),
-                "issued_bf16_flop_per_launch": mfma_flop,
+                "issued_f16_flop_per_launch": mfma_flop,
                 "useful_fp32_flop_per_launch": 2 * CORR["B"] * CORR["H"] * CORR["W"] * 441 * CORR["C"],
-                "note": "issued = useful x 6 (products of the split) / 0.766 (band); the split itself is VALU work that "
-                        "does not overlap with MFMA issue on a SIMD (DESIGN.md 4.1)"})(
-                6 * 2 * CORR["B"] * CORR["H"] * CORR["W"] * 576 * CORR["C"]),
+                "note": "issued = 3 products of the two-term f16 split x the 4x4-block band (44 of 64 block pairs per "
+                        "row-block pair); the kernel is bound by instruction issue and LDS, not by the matrix pipe (DESIGN.md 4.1)"})(
+                480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -7,6 +7,7 @@
 //                                   4 no stores, 8 no operand reads, 16 no split / LDS staging writes)
 //   backward variants: 100 + v      instantiations of correlation_mfma_bwd.hip
 #pragma once
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -17,6 +18,13 @@ int fn2_debug_correlation_forward(const void *in1, const void *in2, void *out, i
 int fn2_debug_correlation_backward(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,
                                    int dtype, int B, int C, int H, int W, int pad_size, int kernel_size,
                                    int max_displacement, int stride1, int stride2, int variant, void *stream);
+/* resample2d with profiling switches in `flags` (bit 8: untiled kernels, bits 9-11: backward ablations, bits 12-13: tile
+ * height 1 = 48, 2 = 32, 3 = 64 rows); the public entry points only look at bilinear != 0 */
+int fn2_debug_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
+                                 int B, int C, int Hi, int Wi, int H, int W, int kernel_size, int bilinear, int flags, void *stream);
+int fn2_debug_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow, const float *grad_out,
+                                  float *grad_img, float *grad_flow, int B, int C, int Hi, int Wi, int H, int W,
+                                  int kernel_size, int bilinear, int flags, void *stream);
 /* device buffer (>= 64 KB) that forward variant 5064 dumps its s_memtime stamps into; NULL = none */
 void fn2_debug_set_buffer(void *device_ptr);
 #ifdef __cplusplus

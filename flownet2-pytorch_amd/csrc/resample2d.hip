@@ -14,6 +14,7 @@
 // Arithmetic order follows the reference so the gather results are bit-identical to its source
 // semantics: bilinear weights in double, each term rounded to float, float accumulation.
 #include "fn2_common.h"
+#include "fn2_debug.h"
 
 namespace fn2 {
 
@@ -609,9 +610,11 @@ static inline unsigned stream_grid(long nthreads)
 
 } // namespace fn2
 
-extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
-                                      int B, int C, int Hi, int Wi, int H, int W,
-                                      int kernel_size, int bilinear, void *stream)
+// `bilinear`: bit 0 = bilinear (else nearest); bits 8.. = profiling switches that only fn2_debug_resample2d_* set
+// (bit 8: untiled kernels, bits 9-11: backward ablations, bits 12-13: tile height)
+static int resample2d_forward_impl(const float *img, const int64_t *img_strides, const float *flow, float *out,
+                                   int B, int C, int Hi, int Wi, int H, int W,
+                                   int kernel_size, int bilinear, void *stream)
 {
     using namespace fn2;
     if (B < 0 || C < 0 || Hi < 1 || Wi < 1 || H < 0 || W < 0) return FN2_EINVAL;
@@ -652,10 +655,25 @@ extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strid
     return launch_status();
 }
 
-extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
-                                       const float *grad_out, float *grad_img, float *grad_flow,
-                                       int B, int C, int Hi, int Wi, int H, int W,
-                                       int kernel_size, int bilinear, void *stream)
+extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
+                                      int B, int C, int Hi, int Wi, int H, int W,
+                                      int kernel_size, int bilinear, void *stream)
+{
+    return resample2d_forward_impl(img, img_strides, flow, out, B, C, Hi, Wi, H, W, kernel_size, bilinear != 0 ? 1 : 0, stream);
+}
+
+extern "C" int fn2_debug_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
+                                            int B, int C, int Hi, int Wi, int H, int W,
+                                            int kernel_size, int bilinear, int flags, void *stream)
+{
+    return resample2d_forward_impl(img, img_strides, flow, out, B, C, Hi, Wi, H, W, kernel_size,
+                                   (bilinear != 0 ? 1 : 0) | (flags & ~0xff), stream);
+}
+
+static int resample2d_backward_impl(const float *img, const int64_t *img_strides, const float *flow,
+                                    const float *grad_out, float *grad_img, float *grad_flow,
+                                    int B, int C, int Hi, int Wi, int H, int W,
+                                    int kernel_size, int bilinear, void *stream)
 {
     using namespace fn2;
     // both reference backward kernels ignore the bilinear flag; bit 8 of it selects the
@@ -698,10 +716,29 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
     return launch_status();
 }
 
+extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
+                                       const float *grad_out, float *grad_img, float *grad_flow,
+                                       int B, int C, int Hi, int Wi, int H, int W,
+                                       int kernel_size, int bilinear, void *stream)
+{
+    return resample2d_backward_impl(img, img_strides, flow, grad_out, grad_img, grad_flow, B, C, Hi, Wi, H, W, kernel_size,
+                                    bilinear != 0 ? 1 : 0, stream);
+}
+
+extern "C" int fn2_debug_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
+                                             const float *grad_out, float *grad_img, float *grad_flow,
+                                             int B, int C, int Hi, int Wi, int H, int W,
+                                             int kernel_size, int bilinear, int flags, void *stream)
+{
+    return resample2d_backward_impl(img, img_strides, flow, grad_out, grad_img, grad_flow, B, C, Hi, Wi, H, W, kernel_size,
+                                    (bilinear != 0 ? 1 : 0) | (flags & ~0xff), stream);
+}
+
 extern "C" int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, float div_flow,
                                       int B, int C, int H, int W, int bilinear, void *stream)
 {
     using namespace fn2;
+    bilinear = bilinear != 0 ? 1 : 0;
     if (B < 0 || C < 1 || H < 1 || W < 1 || !(div_flow == div_flow) || div_flow == 0.0f) return FN2_EINVAL;
     if ((long)B * H * W == 0) return FN2_OK;
     if (!pair || !flow || !out) return FN2_EINVAL;

@@ -22,7 +22,8 @@ EXPORTS = [
 ]
 
 # profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design
-DEBUG_EXPORTS = ["fn2_debug_correlation_forward", "fn2_debug_correlation_backward", "fn2_debug_set_buffer"]
+DEBUG_EXPORTS = ["fn2_debug_correlation_forward", "fn2_debug_correlation_backward", "fn2_debug_set_buffer",
+                 "fn2_debug_resample2d_forward", "fn2_debug_resample2d_backward"]
 
 _lib = None
 

@@ -24,7 +24,10 @@ class Resample2dFunction(Function):
         ctx.kernel_size, ctx.bilinear = kernel_size, bilinear
         channels = input1.size(1)
         batch, _, height, width = input2.size()
-        output = input1.new_zeros((batch, channels, height, width))
+        if int(kernel_size) != 1:
+            raise ValueError("Resample2d: kernel_size must be 1 (larger windows read out of bounds in the reference kernel, "
+                             "resample2d_kernel.cu:41-60, and are not implemented here)")
+        output = input1.new_empty((batch, channels, height, width))   # fully written by the kernel
         resample2d_cuda.forward(input1, input2, output, kernel_size, bilinear)
         return output
 
@@ -34,7 +37,7 @@ class Resample2dFunction(Function):
         grad_output = grad_output.contiguous()
         # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero
         grad_input1 = torch.zeros_like(input1, memory_format=torch.contiguous_format)
-        grad_input2 = torch.zeros_like(input2, memory_format=torch.contiguous_format)
+        grad_input2 = torch.empty_like(input2, memory_format=torch.contiguous_format)   # fully written
         resample2d_cuda.backward(input1, input2, grad_output, grad_input1, grad_input2, ctx.kernel_size, ctx.bilinear)
         return grad_input1, grad_input2, None, None
 
@@ -42,6 +45,8 @@ class Resample2dFunction(Function):
 class Resample2d(nn.Module):
     def __init__(self, kernel_size=1, bilinear=True):
         super().__init__()
+        if int(kernel_size) != 1:
+            raise ValueError("Resample2d: kernel_size must be 1 (see Resample2dFunction)")
         self.kernel_size = kernel_size
         self.bilinear = bilinear
 

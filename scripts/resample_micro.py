@@ -1,4 +1,4 @@
-"""Micro-benchmark of the resample2d kernels through the C ABI (bilinear flag bits 8.. select profiling variants)."""
+"""Micro-benchmark of the resample2d kernels through the C ABI (fn2_debug_resample2d_*: flag bits 8.. select profiling variants)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
@@ -29,9 +29,9 @@ def timeit(fn, n=20):
 for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth)):
     print(name)
     for flags, lab in ((1, "fwd tiled"), (1 | 0x1000, "fwd tiled 48x64"), (1 | 0x2000, "fwd tiled 32x64"), (1 | 0x100, "fwd untiled")):
-        t = timeit(lambda: lib.fn2_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, flags, st))
+        t = timeit(lambda: lib.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
         print("   %-28s %.1f us" % (lab, t))
     for flags, lab in ((1, "bwd tiled"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"), (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
                        (1 | 0xE00, "bwd tiled, none of them"), (1 | 0x100, "bwd untiled")):
-        t = timeit(lambda: lib.fn2_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, flags, st))
+        t = timeit(lambda: lib.fn2_debug_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
         print("   %-28s %.1f us" % (lab, t))

@@ -854,3 +854,59 @@ def test_multiscale_l1_epe(dev, shape):
             # sign() flips where |out - t_i| is at rounding level: allow a handful of such elements
             diff = (a.grad - 2.0 * b.grad).abs()
             assert int((diff > 1e-9).sum()) <= max(2, a.numel() // 5000), int((diff > 1e-9).sum())
+
+
+def test_multiscale_l1_double_backward_and_layouts(dev):
+    """the fused loss must not rescale its cached gradients in place (second backward over the same graph,
+    gradient scalers), must take non-contiguous predictions (channels_last), and accepts a single tensor (eval branch of
+    the reference, losses.py:80-83)."""
+    from losses_fused import MultiScaleL1
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 128, 192
+    target = (torch.randn(B, 2, H, W, generator=g) * 5).to(dev)
+    outs = [(torch.randn(B, 2, H // (4 << i), W // (4 << i), generator=g) * 0.3).to(dev) for i in range(5)]
+    crit = MultiScaleL1()
+    of = [o.clone().requires_grad_(True) for o in outs]
+    loss, _ = crit(tuple(of), target)
+    (3.0 * loss).backward(retain_graph=True)
+    first = [o.grad.clone() for o in of]
+    for o in of:
+        o.grad = None
+    (3.0 * loss).backward()
+    for a, b in zip(of, first):
+        assert torch.equal(a.grad, b), "second backward over the same graph changed the gradients"
+    # non-contiguous predictions: same values, gradients arrive
+    nc = [o.clone().to(memory_format=torch.channels_last).requires_grad_(True) for o in outs]
+    loss2, _ = crit(tuple(nc), target)
+    loss2.backward()
+    assert abs(float(loss2.detach()) - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach())))
+    for a, b in zip(nc, first):
+        assert a.grad is not None and float((3.0 * a.grad - b).abs().max()) <= 1e-7
+    # single full-resolution tensor
+    full = (torch.randn(B, 2, H, W, generator=g)).to(dev)
+    l1, epe = crit(full, target)
+    assert abs(float(l1) - float((full - target).abs().mean())) <= 1e-6
+    assert abs(float(epe) - float(torch.norm(target - full, p=2, dim=1).mean())) <= 1e-5
+
+
+def test_resample2d_flag_and_kernel_size_handling(dev):
+    """any non-zero `bilinear` means bilinear at the public C entry points (no profiling bits there), and
+    kernel_size != 1 is refused when the module is built, with a clear message."""
+    import ctypes
+    import fn2_capi
+    from networks.resample2d_package.resample2d import Resample2d
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(2, 3, 32, 64, generator=g).to(dev)
+    flow = (torch.randn(2, 2, 32, 64, generator=g) * 3).to(dev)
+    outs = []
+    for flag in (1, 2, 0x100, 0x1001):
+        out = torch.empty_like(img)
+        rc = fn2_capi.lib().fn2_resample2d_forward(ctypes.c_void_p(img.data_ptr()), None, ctypes.c_void_p(flow.data_ptr()),
+                                                   ctypes.c_void_p(out.data_ptr()), 2, 3, 32, 64, 32, 64, 1, flag, None)
+        assert rc == 0
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    with pytest.raises(ValueError, match="kernel_size must be 1"):
+        Resample2d(kernel_size=2)
