@@ -17,18 +17,18 @@
 // 6 neighbour row blocks u itself (rows 4rg - 10 + 4u .. +3): the sum over neighbours stays in registers, no atomics,
 // deterministic.  Per u:
 //   G image   the 16 (centre row ai, neighbour row bi) combinations x 21 displacement columns x 64 pixels of gO that the
-//             pair (rg, u) touches -- the forward's output tile -- as f16 hi / lo planes [ai][bi][ti][x] in LDS (strides
-//             padded so that the gather below is conflict-free).  The G operand of (centre block a, neighbour block pair j)
-//             is a GATHER from it: lane (pixel, k group) picks 8 values with ds_read_u16 (one address register +
-//             immediates; values outside the 21-wide band come from a zero word); gathered once per u into registers
-//             and reused for the 4 channel tiles.
+//             pair (rg, u) touches -- the forward's output tile -- as 32-bit (hi f16 | lo f16) elements [ai][bi][ti][x'] in LDS
+//             (strides padded so that the gather below is conflict-free).  The G operand of (centre block a, neighbour
+//             block pair j) is a GATHER from it: lane (pixel, k group) picks 8 elements with ds_read_b32 (one address
+//             register + immediates; values outside the 21-wide band come from a zero word) and unzips them with 8 v_perm;
+//             gathered once per u into registers and reused for the 4 channel tiles.
 //   X tile    4 neighbour rows x 64 pixels x 32 channels per chunk, the LDS image of the forward kernel (8-byte chunks of
 //             4 lattice columns, [term][parity][channel][column block][row]): the X operand of (channel tile, block pair)
 //             is two plain ds_read_b128 (hi, lo) -- the neighbour pixels of one channel are contiguous.
 // Waves are specialised as in the forward: waves 0-7 stage (buffer loads whose range check returns zeros outside the
 // image / the displacement range, split, LDS writes), waves 8-15 gather and run the MFMAs: wave w takes x parity w&1
 // and the centre column blocks of role w>>1 ({0,3},{1,2},{4,7},{5,6}: 6 (block, pair) products each) x 4 channel tiles.
-// Three barriers per u: [gather block 0's operands | write both X chunks] [MFMA block 0, gather block 1 | -] [MFMA block 1 | write G(u+1)].
+// Two barriers per u: [gather the 6 G operands | write both X chunks] [72 MFMAs | write G(u+1)].
 // Epilogue: accumulators -> LDS [channel][row][x] (16-byte slots rotated) -> rows of 256 B, scaled by 1/C; outputs that
 // came out non-finite (an operand did not fit an f16) are recomputed in plain fp32.
 #include <type_traits>
@@ -52,13 +52,21 @@ constexpr int CG = 64, NCT = CG / 16;             // channels per task, channel 
 constexpr int CK = 32;                            // channels per X chunk (2 tiles)
 // X chunk image (bytes), as in correlation_f16x2.hip
 constexpr int CHS = 288, PARS = CK * CHS, XTERM = 2 * PARS, XBUF = 2 * XTERM;   // 9216, 18432, 36864
-// G image (bytes): [term][ai][bi][ti][64 x f16]; strides padded: bi stride = 64 mod 128, ai stride = 16 mod 128, so that the
-// 32 lanes of a gather (aj: 4 B apart, ai, bi parity) hit 32 distinct banks
-constexpr int G_TI = 128, G_BI = D * G_TI + 32, G_AI = 4 * G_BI + 16, GTERM = 4 * G_AI, GIMG = 2 * GTERM;   // 2720, 10896, 43584, 87168
-constexpr int X_OFS = GIMG, ZERO_OFS = X_OFS + 2 * XBUF, LDS_BYTES = ZERO_OFS + 64;                          // 87168, 160896, 160960
+// G image (bytes): [ai][bi][ti][x'] with 32-bit elements (hi f16 | lo f16 << 16) and x' = 32 * x parity + lattice column.
+// Strides are padded so that the 32 lanes of a gather (aj, ai, bi parity) hit 32 distinct banks: a lane's aj moves the
+// column for FLIP 0 but the displacement row for FLIP 1, so the row stride is 256 B for FLIP 0 and 260 B for FLIP 1;
+// bi stride = 32 mod 64 (two bi = 16 banks), ai stride = 16 mod 128 (4 banks)
+template <int FLIP> struct GL {
+    static constexpr int TI = FLIP ? 260 : 256;
+    static constexpr int BI = FLIP ? D * 260 + 12 : D * 256 + 32;   // 5472 / 5408
+    static constexpr int AI = 4 * BI + 16;                          // 21904 / 21648
+    static constexpr int IMG = 4 * AI;                              // 87616 / 86592
+};
+static_assert(GL<0>::BI % 64 == 32 && GL<1>::BI % 64 == 32 && GL<0>::AI % 128 == 16 && GL<1>::AI % 128 == 16, "gather bank pattern");
+constexpr int GIMG = GL<1>::IMG;
+constexpr int X_OFS = GIMG, ZERO_OFS = X_OFS + 2 * XBUF, LDS_BYTES = ZERO_OFS + 64;                          // 87616, 161344, 161408
 constexpr int E_BYTES = CG * 4 * 64 * 4;          // epilogue image [64 channels][4 rows][64 x] floats, aliases the G image
 static_assert(E_BYTES <= GIMG && LDS_BYTES <= 163840, "LDS budget");
-static_assert(G_BI % 128 == 32 && (2 * G_BI) % 128 == 64 && G_AI % 128 == 16, "gather bank pattern");
 
 struct Args {
     const float *nbr[2];   // [0] = in2 (neighbours for gradInput1), [1] = in1 (for gradInput2)
@@ -91,7 +99,7 @@ __host__ __device__ constexpr int frag_sub(int role, int ab, int j)   // index a
     }
     return -1;
 }
-constexpr int NF = 4;   // block pairs a centre block can meet (2 .. 4)
+constexpr int NF = 6;   // (centre block, block pair) products of a wave
 static_assert(frag_idx(0, 1, 3) == 5 && frag_idx(1, 1, 3) == -1 && frag_idx(1, 1, 2) == 5 && frag_idx(2, 1, 3) == 5 && frag_idx(3, 1, 3) == 5,
               "6 products per role");
 
@@ -140,7 +148,7 @@ __device__ __forceinline__ float exact_grad(const Args &p, int flip, int n, int 
 }
 
 struct XSet { u4 v[2][2]; };       // one X chunk of one lane: [slot][half] x 16 B (8 pixels)
-constexpr int NGI = 11;            // G items (float4) per staging lane: 16 planes x 21 x 16 = 5376 = 10.5 x 512
+constexpr int NGI = 6;             // G items (8 pixels) per staging lane: 16 planes x 21 x 8 = 2688 = 5.25 x 512
 
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no stores, 8 no gathers / operand reads,
 //      16 no split / LDS staging writes
@@ -222,9 +230,9 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
 
     if (is_stage) {
         // ================= staging waves =================
-        // G items: 16 B of gO each.  Item k (0 .. 10) of a lane: plane = 2 w8 + (lane >> 5), ti = 2k + ((lane >> 4) & 1),
-        // x4 = lane & 15 -- LDS offset and gO offset are linear in k (immediates / scalar offsets), validity does not
-        // depend on k except for ti = 21 (k = 10, odd half)
+        // G items: 8 pixels of one gO row each (two 16-byte loads).  Item k (0 .. 5) of a lane: plane = 2 w8 + (lane >> 5),
+        // ti = 4k + ((lane >> 3) & 3), piece = lane & 7 -- LDS offset and gO offset are linear in k (immediates / scalar
+        // offsets); only ti <= 20 exists (k = 5: the first quarter)
         // X items (as the forward's tiles): slot k covers channels 16k .. 16k+15 of the chunk
         const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
         const int s_row = (lane >> 2) & 3;
@@ -240,38 +248,49 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const int g_plane = 2 * w8 + (ln >> 5), g_ai = g_plane >> 2, g_bi = g_plane & 3;
-            const int g_tih = (ln >> 4) & 1, g_x4 = ln & 15;
-            const int g_ofs = g_ai * G_AI + g_bi * G_BI + g_tih * G_TI + g_x4 * 8;      // + k * 2 * G_TI
+            const int g_tiq = (ln >> 3) & 3, g_pc = ln & 7;
+            const int g_ti = tk.flip ? GL<1>::TI : GL<0>::TI;                               // row stride of this task's image
+            const int g_ofs = tk.flip ? g_ai * GL<1>::AI + g_bi * GL<1>::BI + g_tiq * GL<1>::TI + g_pc * 16
+                                      : g_ai * GL<0>::AI + g_bi * GL<0>::BI + g_tiq * GL<0>::TI + g_pc * 16;   // + k * 4 * row stride; x parity 1: + 128
             // FLIP 0: tj = 4u + bi - ai, gO row = centre row ai.   FLIP 1: tj = 20 - 4u - bi + ai, gO row = neighbour row bi
             const int g_tj0 = tk.flip ? 20 - g_bi + g_ai : g_bi - g_ai;                  // tj at u = 0; +-4 per u
             const int g_il0 = tk.flip ? 4 * tk.rg - DR + g_bi : 4 * tk.rg + g_ai;         // gO lattice row at u = 0; +4 per u for FLIP 1
-            const int g_base = ((g_tj0 * D + g_tih) * p.H + 2 * g_il0 + tk.py) * p.W + 4 * g_x4;   // element offset at u = 0, k = 0
+            const int g_base = ((g_tj0 * D + g_tiq) * p.H + 2 * g_il0 + tk.py) * p.W + 8 * g_pc;   // element offset at u = 0, k = 0
             const int g_du = tk.flip ? (-4 * D * p.H + 8) * p.W : 4 * D * p.H * p.W;      // element offset step per u
-            const int g_dk = 2 * p.H * p.W;                                               // ... per k (two ti planes)
-            u4 gv[NGI];
+            const int g_dk = 4 * p.H * p.W;                                               // ... per k (four ti planes)
+            u4 gv[NGI][2];
             auto g_issue = [&](int u) {
                 const int tj = tk.flip ? g_tj0 - 4 * u : g_tj0 + 4 * u;
                 const int il = tk.flip ? g_il0 + 4 * u : g_il0;
-                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL && 4 * g_x4 < p.W;
+                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL && 8 * g_pc < p.W;
                 const unsigned vo = ok ? (unsigned)((g_base + u * g_du) * 4) : 0x80000000u;
-                const unsigned vo_last = g_tih ? 0x80000000u : vo;                        // k = 10: ti = 20 / 21
+                const unsigned vo_last = g_tiq ? 0x80000000u : vo;                        // k = 5: ti = 20 .. 23
 #pragma unroll
                 for (int k = 0; k < NGI; ++k) {
-                    if (VAR & 2) gv[k] = (u4)(0x3c000000u + lane);
-                    else gv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)(k == NGI - 1 ? vo_last : vo), k * g_dk * 4, 0);
+                    const unsigned v = k == NGI - 1 ? vo_last : vo;
+                    if (VAR & 2) { gv[k][0] = (u4)(0x3c000000u + lane); gv[k][1] = gv[k][0]; continue; }
+                    gv[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)v, k * g_dk * 4, 0);
+                    gv[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)(v + 16), k * g_dk * 4, 0);
                 }
+            };
+            // one value -> (f16(x) | f16(x - f16(x)) << 16)
+            auto word = [&](unsigned hpair, bool hi_half, float x) -> unsigned {
+                const float r = hi_half ? resid_hi(hpair, x) : resid_lo(hpair, x);
+                return pk_f16(x, r);
             };
             auto g_write = [&]() {
 #pragma unroll
                 for (int k = 0; k < NGI; ++k) {
-                    if (VAR & 16) { asm volatile("" ::"v"(gv[k])); continue; }
-                    const f4 x = __builtin_bit_cast(f4, gv[k]);
-                    const unsigned h01 = pk_f16(x[0], x[1]), h23 = pk_f16(x[2], x[3]);
-                    const unsigned l01 = pk_f16(resid_lo(h01, x[0]), resid_hi(h01, x[1]));
-                    const unsigned l23 = pk_f16(resid_lo(h23, x[2]), resid_hi(h23, x[3]));
-                    if (k < NGI - 1 || !g_tih) {
-                        *(FN2_LDS(u2) *)(smem + g_ofs + k * 2 * G_TI) = (u2){h01, h23};
-                        *(FN2_LDS(u2) *)(smem + g_ofs + k * 2 * G_TI + GTERM) = (u2){l01, l23};
+                    if (VAR & 16) { asm volatile("" ::"v"(gv[k][0]), "v"(gv[k][1])); continue; }
+                    const f4 x0 = __builtin_bit_cast(f4, gv[k][0]), x1 = __builtin_bit_cast(f4, gv[k][1]);
+                    if (k < NGI - 1 || !g_tiq) {
+#pragma unroll
+                        for (int par = 0; par < 2; ++par) {
+                            const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
+                            const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
+                            const u4 w = {word(h01, false, e0), word(h01, true, e1), word(h23, false, e2), word(h23, true, e3)};
+                            *(FN2_LDS(u4) *)(smem + g_ofs + k * 4 * g_ti + par * 128) = w;
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -317,17 +336,15 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
             g_issue(1);
             __syncthreads();                                   // (A) G(0) complete
             for (int u = 0; u < NU; ++u) {
-                // phase 1 (the matrix waves gather the first centre block's operands): both X chunks of u
+                // phase 1 (the matrix waves gather the G operands of u): both X chunks of u
                 x_write(X0, smem + X_OFS);
                 x_write(X1, smem + X_OFS + XBUF);
                 if (u + 1 < NU) { x_issue(X0, u + 1, 0); x_issue(X1, u + 1, 1); }
-                __syncthreads();                               // (B)
-                // phase 2 (MFMAs of the first centre block, gather of the second): nothing to write, the image is in use
-                __syncthreads();                               // (C) the G image is free
-                // phase 3 (MFMAs of the second centre block): G(u+1)
+                __syncthreads();                               // (B) the G image is free, the X chunks complete
+                // phase 2 (all MFMAs of u): G(u+1)
                 if (u + 1 < NU) g_write();
                 if (u + 2 < NU) g_issue(u + 2);
-                __syncthreads();                               // (A')
+                __syncthreads();                               // (A') the X buffers are free, G(u+1) complete
             }
             __syncthreads();                                   // epilogue image complete
             store_rows(tk);
@@ -355,115 +372,120 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
         for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-        h8 gh[NF], gl[NF];   // the operands of ONE centre block at a time
+        h8 gh[NF], gl[NF];   // the G operands of the wave's 6 (centre block, block pair) products
 
         // Gather of the G operands.  Slot s of k group g = neighbour (block m = 2j + blk, row bi = 2gg + (s>>2), column bj = s&3)
         // with blk = g>>1, gg = g&1, dm = m - a:
-        //   FLIP 0: ti = 4 dm + bj - aj + 10, x = 8a + 2aj + par      FLIP 1: ti = 10 - 4 dm - bj + aj, x = 8m + 2bj + par
-        // byte offset = ai G_AI + bi G_BI + ti 128 + 2x = lane part + slot part + (a, j) part; the lane part is recomputed in
+        //   FLIP 0: ti = 4 dm + bj - aj + 10, x' = 32 par + 4a + aj      FLIP 1: ti = 10 - 4 dm - bj + aj, x' = 32 par + 4m + bj
+        // byte offset = ai AI + bi BI + ti TI + 4 x' = lane part + slot part + (a, j) part; the lane part is recomputed in
         // every call from an opaque copy of the lane id (hoisted out of the u loop it would be 48 live addresses).
-        auto gather = [&](auto role_c, auto abc) {
+        auto gather = [&](auto role_c) {
             constexpr int R = decltype(role_c)::value;
-            constexpr int ab = decltype(abc)::value;
-            constexpr int a = a_blk(R, ab);
+            typedef GL<FLIP> L;
             int l2 = lane;
             asm volatile("" : "+v"(l2));
             const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = l2 >> 5, gg = (l2 >> 4) & 1;
-            const int lbase = FLIP ? ai * G_AI + 2 * gg * G_BI + (DR - 4 * blk + aj) * G_TI - 3 * (G_TI - 4) + 16 * blk + 2 * xpar
-                                   : ai * G_AI + 2 * gg * G_BI + (DR + 4 * blk - aj) * G_TI + 4 * aj + 2 * xpar;
+            const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * (L::TI - 4) + 16 * blk + 128 * xpar
+                                   : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 4 * aj + 128 * xpar;
             const int t0 = FLIP ? DR - 4 * blk + aj : DR + 4 * blk - aj;        // ti = t0 -+ 4 (2j - a) -+ bj
-            static_for<0, 4>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int fi = frag_sub(R, ab, j);
-                if constexpr (fi >= 0) {
-                    constexpr int dj = 2 * j - a;                             // dm = dj + blk
-                    constexpr int pconst = FLIP ? -4 * dj * G_TI + 32 * j : 4 * dj * G_TI + 16 * a;
-                    constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
-                    const int fbase = lbase + pconst;
-                    const int tb = FLIP ? t0 - 4 * dj : t0 + 4 * dj;          // ti of bj = 0
-                    s8 vh, vl;
-                    static_for<0, 8>([&](auto sc) {
-                        constexpr int s = decltype(sc)::value;
-                        constexpr int bjs = s & 3, bis = s >> 2;
-                        constexpr int sconst = FLIP ? bis * G_BI + (3 - bjs) * (G_TI - 4) : bis * G_BI + bjs * G_TI;
-                        int ofs = fbase + sconst, ofl = ofs + GTERM;
-                        if constexpr (check) {
-                            const int ti = FLIP ? tb - bjs : tb + bjs;
-                            const bool ok = ti >= 0 && ti < D;
-                            ofs = ok ? ofs : ZERO_OFS;
-                            ofl = ok ? ofl : ZERO_OFS;
+            static_for<0, 2>([&](auto abc) {
+                constexpr int ab = decltype(abc)::value;
+                constexpr int a = a_blk(R, ab);
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int fi = frag_idx(R, ab, j);
+                    if constexpr (fi >= 0) {
+                        constexpr int dj = 2 * j - a;                             // dm = dj + blk
+                        constexpr int pconst = FLIP ? -4 * dj * L::TI + 32 * j : 4 * dj * L::TI + 16 * a;
+                        constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
+                        const int fbase = lbase + pconst;
+                        const int tb = FLIP ? t0 - 4 * dj : t0 + 4 * dj;          // ti of bj = 0
+                        unsigned w[8];
+                        static_for<0, 8>([&](auto sc) {
+                            constexpr int s = decltype(sc)::value;
+                            constexpr int bjs = s & 3, bis = s >> 2;
+                            constexpr int sconst = FLIP ? bis * L::BI + (3 - bjs) * (L::TI - 4) : bis * L::BI + bjs * L::TI;
+                            int ofs = fbase + sconst;
+                            if constexpr (check) {
+                                const int ti = FLIP ? tb - bjs : tb + bjs;
+                                ofs = (ti >= 0 && ti < D) ? ofs : ZERO_OFS;
+                            }
+                            w[s] = (VAR & 8) ? 0x3c00u : *reinterpret_cast<const unsigned *>(smem + ofs);
+                        });
+                        u4 vh, vl;   // (hi, hi) and (lo, lo) pairs of consecutive slots
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            vh[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u);
+                            vl[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u);
                         }
-                        if (VAR & 8) { vh[s] = (short)0x3c00; vl[s] = 0; }
-                        else {
-                            vh[s] = *reinterpret_cast<const short *>(smem + ofs);
-                            vl[s] = *reinterpret_cast<const short *>(smem + ofl);
-                        }
-                    });
-                    gh[fi] = __builtin_bit_cast(h8, vh);
-                    gl[fi] = __builtin_bit_cast(h8, vl);
-                    __builtin_amdgcn_sched_barrier(0);   // one operand at a time: 16 loads in flight
-                }
+                        gh[fi] = __builtin_bit_cast(h8, vh);
+                        gl[fi] = __builtin_bit_cast(h8, vl);
+                        __builtin_amdgcn_sched_barrier(0);   // one operand at a time: 8 loads in flight
+                    }
+                });
             });
         };
-        // MFMAs of one centre block over both X chunks (4 channel tiles): D[channel][pixel] += X[channel][q] * G[q][pixel]
-        auto mma = [&](auto role_c, auto abc) {
+        // All MFMAs of u: D[channel][pixel] += X[channel][q] * G[q][pixel].  The X operands of a block pair and two channel
+        // tiles are read once and used by both centre blocks of the wave.
+        auto mma = [&](auto role_c) {
             constexpr int R = decltype(role_c)::value;
-            constexpr int ab = decltype(abc)::value;
             static_for<0, 4>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int fi = frag_sub(R, ab, j);
-                if constexpr (fi >= 0) {
-                    // the X operands of the 4 channel tiles first, then the three products tile by tile: consecutive MFMAs
-                    // work on different accumulators
-                    h8 xh[NCT], xl[NCT];
+                constexpr int f0 = frag_idx(R, 0, j), f1 = frag_idx(R, 1, j);
+                if constexpr (f0 >= 0 || f1 >= 0) {
+                    static_for<0, 2>([&](auto chc) {
+                        constexpr int ch = decltype(chc)::value;
+                        const char *buf = smem + X_OFS + ch * XBUF;
+                        h8 xh[2], xl[2];
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const char *buf = smem + X_OFS + (ct >> 1) * XBUF + (ct & 1) * 16 * CHS;
-                        if (VAR & 8) { xh[ct] = (h8)((_Float16)1.0f); xl[ct] = xh[ct]; }
-                        else {
-                            xh[ct] = *reinterpret_cast<const h8 *>(buf + xb + j * 64);
-                            xl[ct] = *reinterpret_cast<const h8 *>(buf + xb + j * 64 + XTERM);
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            if (VAR & 8) { xh[c2] = (h8)((_Float16)1.0f); xl[c2] = xh[c2]; }
+                            else {
+                                xh[c2] = *reinterpret_cast<const h8 *>(buf + xb + c2 * 16 * CHS + j * 64);
+                                xl[c2] = *reinterpret_cast<const h8 *>(buf + xb + c2 * 16 * CHS + j * 64 + XTERM);
+                            }
                         }
-                    }
-                    if (VAR & 1) {
+                        if (VAR & 1) {
+                            asm volatile("" ::"v"(xh[0]), "v"(xl[0]), "v"(xh[1]), "v"(xl[1]));
+                        } else {
+                            static_for<0, 3>([&](auto prc) {
+                                constexpr int pr = decltype(prc)::value;
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) asm volatile("" ::"v"(xh[ct]), "v"(xl[ct]));
-                    } else {
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ct], gh[fi], acc[ab][ct], 0, 0, 0);
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ct], gl[fi], acc[ab][ct], 0, 0, 0);
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) acc[ab][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[ct], gh[fi], acc[ab][ct], 0, 0, 0);
-                    }
+                                for (int c2 = 0; c2 < 2; ++c2) {
+                                    if constexpr (f0 >= 0)
+                                        acc[0][2 * ch + c2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 2 ? xl[c2] : xh[c2], pr == 1 ? gl[f0 >= 0 ? f0 : 0] : gh[f0 >= 0 ? f0 : 0], acc[0][2 * ch + c2], 0, 0, 0);
+                                    if constexpr (f1 >= 0)
+                                        acc[1][2 * ch + c2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 2 ? xl[c2] : xh[c2], pr == 1 ? gl[f1 >= 0 ? f1 : 0] : gh[f1 >= 0 ? f1 : 0], acc[1][2 * ch + c2], 0, 0, 0);
+                                }
+                            });
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 }
             });
         };
-        auto gather_d = [&](auto abc) {
+        auto gather_d = [&]() {
             switch (role) {
-            case 0: gather(std::integral_constant<int, 0>{}, abc); break;
-            case 1: gather(std::integral_constant<int, 1>{}, abc); break;
-            case 2: gather(std::integral_constant<int, 2>{}, abc); break;
-            default: gather(std::integral_constant<int, 3>{}, abc); break;
+            case 0: gather(std::integral_constant<int, 0>{}); break;
+            case 1: gather(std::integral_constant<int, 1>{}); break;
+            case 2: gather(std::integral_constant<int, 2>{}); break;
+            default: gather(std::integral_constant<int, 3>{}); break;
             }
         };
-        auto mma_d = [&](auto abc) {
+        auto mma_d = [&]() {
             switch (role) {
-            case 0: mma(std::integral_constant<int, 0>{}, abc); break;
-            case 1: mma(std::integral_constant<int, 1>{}, abc); break;
-            case 2: mma(std::integral_constant<int, 2>{}, abc); break;
-            default: mma(std::integral_constant<int, 3>{}, abc); break;
+            case 0: mma(std::integral_constant<int, 0>{}); break;
+            case 1: mma(std::integral_constant<int, 1>{}); break;
+            case 2: mma(std::integral_constant<int, 2>{}); break;
+            default: mma(std::integral_constant<int, 3>{}); break;
             }
         };
 
         __syncthreads();                                       // (A) G(0) complete
         for (int u = 0; u < NU; ++u) {
-            gather_d(std::integral_constant<int, 0>{});        // phase 1: operands of the first centre block
-            __syncthreads();                                   // (B) both X chunks of u complete
-            mma_d(std::integral_constant<int, 0>{});           // phase 2
-            gather_d(std::integral_constant<int, 1>{});
-            __syncthreads();                                   // (C) the G image is free
-            mma_d(std::integral_constant<int, 1>{});           // phase 3
+            gather_d();                                        // phase 1
+            __syncthreads();                                   // (B) both X chunks of u complete, the G image is free
+            mma_d();                                           // phase 2
             __syncthreads();                                   // (A') the X buffers are free; G(u+1) complete
         }
 
