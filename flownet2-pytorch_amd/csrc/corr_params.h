@@ -25,6 +25,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
                        int variant, hipStream_t s);
 
 void corr_f16x2_set_debug_buffer(void *p);
+void *corr_f16x2_get_debug_buffer();
 bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
                         int variant, hipStream_t s);

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 
 static unsigned long long *g_debug_buffer = nullptr;   // profiling only (fn2_debug.h)
 void corr_f16x2_set_debug_buffer(void *p) { g_debug_buffer = static_cast<unsigned long long *>(p); }
+void *corr_f16x2_get_debug_buffer() { return g_debug_buffer; }
 
 bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2)
 {

@@ -75,6 +75,7 @@ struct Args {
     int B, C, H, W;        // H even, W % 8 == 0, W <= 64, C % 64 == 0
     int NRG, NCGR;         // row groups per parity, channel groups
     int nflip, flip0;      // 2: both gradients in this launch; 1: only flip0
+    unsigned long long *dbg;   // profiling variant 64 only: s_memtime stamps (fn2_debug_set_buffer)
 };
 
 // centre column blocks of a wave role and the block pairs (2j, 2j+1) they meet
@@ -169,6 +170,19 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const float rC = 1.0f / fC;
     if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero word(s) of the gathers
+    // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and wave 8 (matrix) during the workgroup's first task
+    unsigned long long ts[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ts[i] = 0;
+    auto stamp = [&](int i) __attribute__((always_inline)) { if (VAR & 64) ts[i] = __builtin_amdgcn_s_memtime(); };
+    auto dump = [&]() __attribute__((always_inline)) {
+        if ((VAR & 64) && p.dbg && lane == 0 && (wave == 0 || wave == 8)) {
+            unsigned long long *d = p.dbg + (blockIdx.x * 2 + (wave >> 3)) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = ts[i];
+        }
+    };
+    stamp(0);
 
     struct Task { int flip, n, py, rg, cg; };
     auto get_task = [&](int t) -> Task {
@@ -332,24 +346,37 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
             g_issue(0);
             x_issue(X0, 0, 0);
             x_issue(X1, 0, 1);
+            const bool first = t < (int)gridDim.x;
+            if (first) stamp(1);
             g_write();
             g_issue(1);
+            if (first) stamp(2);
             __syncthreads();                                   // (A) G(0) complete
+            if (first) stamp(3);
             for (int u = 0; u < NU; ++u) {
                 // phase 1 (the matrix waves gather the G operands of u): both X chunks of u
                 x_write(X0, smem + X_OFS);
                 x_write(X1, smem + X_OFS + XBUF);
                 if (u + 1 < NU) { x_issue(X0, u + 1, 0); x_issue(X1, u + 1, 1); }
+                if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
+                if (first && u < 2) stamp(5 + 4 * u);
                 // phase 2 (all MFMAs of u): G(u+1)
                 if (u + 1 < NU) g_write();
                 if (u + 2 < NU) g_issue(u + 2);
+                if (first && u < 2) stamp(6 + 4 * u);
                 __syncthreads();                               // (A') the X buffers are free, G(u+1) complete
+                if (first && u < 2) stamp(7 + 4 * u);
             }
+            if (first) stamp(12);
             __syncthreads();                                   // epilogue image complete
+            if (first) stamp(13);
             store_rows(tk);
             __syncthreads();                                   // image read: LDS free for the next task
+            if (first) stamp(14);
         }
+        stamp(15);
+        dump();
         return;
     }
 
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
 
-    auto run_task = [&](const Task &tk, auto flipc) {
+    auto run_task = [&](const Task &tk, auto flipc, bool first) {
         constexpr int FLIP = decltype(flipc)::value;
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -482,12 +509,18 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
         };
 
         __syncthreads();                                       // (A) G(0) complete
+        if (first) stamp(3);
         for (int u = 0; u < NU; ++u) {
             gather_d();                                        // phase 1
+            if (first && u < 2) stamp(4 + 4 * u);
             __syncthreads();                                   // (B) both X chunks of u complete, the G image is free
+            if (first && u < 2) stamp(5 + 4 * u);
             mma_d();                                           // phase 2
+            if (first && u < 2) stamp(6 + 4 * u);
             __syncthreads();                                   // (A') the X buffers are free; G(u+1) complete
+            if (first && u < 2) stamp(7 + 4 * u);
         }
+        if (first) stamp(12);
 
         // epilogue: D[row = channel 4q + r][col = pixel i] -> Es[c][ai][x], 16-byte slots rotated by 8 ai + 32 ((c>>2)&1)
         auto scatter = [&](auto role_c) {
@@ -513,14 +546,19 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
         default: scatter(std::integral_constant<int, 3>{}); break;
         }
         __syncthreads();
+        if (first) stamp(13);
         store_rows(tk);
         __syncthreads();
+        if (first) stamp(14);
     };
     for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
         const Task tk = get_task(t);
-        if (tk.flip) run_task(tk, std::integral_constant<int, 1>{});
-        else run_task(tk, std::integral_constant<int, 0>{});
+        const bool first = t < (int)gridDim.x;
+        if (tk.flip) run_task(tk, std::integral_constant<int, 1>{}, first);
+        else run_task(tk, std::integral_constant<int, 0>{}, first);
     }
+    stamp(15);
+    dump();
 }
 
 } // namespace hb
@@ -544,13 +582,14 @@ int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, f
     a.B = B; a.C = C; a.H = H; a.W = W;
     a.NRG = (H / 2 + 3) / 4; a.NCGR = C / hb::CG;
     a.nflip = 2; a.flip0 = 0;
+    a.dbg = variant == 64 ? static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer()) : nullptr;
     const long ntasks = 2L * B * 2 * a.NRG * a.NCGR;
     if (ntasks == 0) return FN2_OK;
     if (ntasks > 0x3fffffffL) return FN2_EINVAL;
     const unsigned grid = ntasks < 256 ? (unsigned)ntasks : 256u;   // persistent: one workgroup per CU
 #define FN2_HB(V) case V: hipLaunchKernelGGL((hb::corr_bwd_f16x2<V>), dim3(grid), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31)
+        FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31) FN2_HB(64)
     default: return FN2_EINVAL;
     }
 #undef FN2_HB

@@ -116,6 +116,22 @@ if a.bwd:
             t0 = int(st[:, :7][st[:, :7] > 0].min())
             for w in range(8):
                 print("   wave", w, [int(v) - t0 if v > 0 else None for v in st[w, :7]])
+        if algo == 6064:   # f16x2 backward timeline of each workgroup's first task
+            torch.cuda.synchronize()
+            st = dbg.cpu().view(256, 2, 16)
+            base = st[:, :, 0].min(dim=1, keepdim=True).values.unsqueeze(2)
+            zero = st == 0
+            st = (st - base).double()
+            st[zero] = -1
+            names = ["start", "loads issued", "G(0) written", "barrier A", "u0 ph1 done", "u0 barrier B", "u0 ph2 done", "u0 barrier A'",
+                     "u1 ph1 done", "u1 barrier B", "u1 ph2 done", "u1 barrier A'", "u loop done", "image complete", "task done", "end"]
+            for role, rn in ((0, "staging wave 0"), (1, "matrix wave 8")):
+                print("  ", rn)
+                for i, nm in enumerate(names):
+                    v = st[:, role, i]
+                    v = v[v >= 0]
+                    if len(v):
+                        print("     %-18s mean %8.0f  min %8.0f  max %8.0f   (n=%d)" % (nm, float(v.mean()), float(v.min()), float(v.max()), len(v)))
         if a.check:
             if refb is None:
                 refb = fn2_capi.correlation_backward(in1, in2, gout, a.md, 1, a.md, 1, 2, algo=1)
