@@ -38,108 +38,10 @@
 //     all 36 reads; 33 MFMAs.
 // Epilogue: accumulators -> LDS [plane (ai,bi)][ti][x] (64 floats per row, 16-byte slots rotated by 4 bi + ai: <= 2-way write
 // conflicts, which a ds_write_b32 does not pay for) -> rows leave as 16 B per lane, 4 rows per instruction.
-#include <type_traits>
-
-#include "corr_params.h"
+#include "f16x2_common.h"
 
 namespace fn2 {
 namespace hf {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef short s4 __attribute__((ext_vector_type(4)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
-#define FN2_LDS(T) __attribute__((address_space(3))) T
-
-constexpr int DR = 10, D = 2 * DR + 1, NU = 6;   // displacement radius (lattice), planes per axis, B row blocks per A row block
-constexpr int CK = 32;                            // channels per step
-constexpr int CHS = 288;                          // bytes per channel of one (tile, term, parity) plane: 8 column blocks x 4 rows x 8 B + 32
-constexpr int PARS = CK * CHS;                    // 9216
-constexpr int TERM = 2 * PARS;                    // 18432
-constexpr int TILE = 2 * TERM;                    // 36864
-constexpr int BUF = 2 * TILE;                     // 73728: A tile + B tile of one step
-constexpr int LDS_BYTES = 2 * BUF;                // 147456: two steps
-constexpr int O_RS = 64;                          // epilogue row stride (floats)
-constexpr int O_DUMMY = 16 * D * O_RS;            // sink row for out-of-band entries
-static_assert((O_DUMMY + 64) * 4 <= LDS_BYTES, "epilogue image must fit the operand buffers");
-
-constexpr int MAX_TAB = 768;                      // tasks per batch item the kernel-argument table holds (H <= 512)
-
-struct Args {
-    const float *in1, *in2;
-    float *out;
-    long out_bs;     // elements between batch items of `out`
-    float slope;     // fused LeakyReLU slope (1 = none)
-    int B, C, H, W;  // H even, W % 8 == 0, W <= 64, C % 64 == 0
-    int R_item, P_item;        // tasks per batch item whose B rows meet the image / lie entirely in the padding
-    unsigned magic_r, magic_p; // ceil(2^32 / R_item), ceil(2^32 / P_item)
-    unsigned long long *dbg;   // profiling variant 64 only: where the s_memtime stamps go (fn2_debug_set_buffer)
-    unsigned tab[MAX_TAB / 2];     // 16-bit entries (rg << 4 | py << 3 | u): the R_item real, then the P_item zero-only tasks of an item
-};
-
-// wave roles: A column blocks of role r, and the B column blocks they meet
-constexpr int NAB = 2;                            // A blocks per wave
-__host__ __device__ constexpr int a_blk(int role, int ab) { return role == 0 ? (ab ? 3 : 0) : role == 1 ? (ab ? 2 : 1) : role == 2 ? (ab ? 7 : 4) : (ab ? 6 : 5); }
-__host__ __device__ constexpr int m_lo(int role) { return role == 0 ? 0 : role == 1 ? 0 : role == 2 ? 1 : 2; }
-__host__ __device__ constexpr int m_hi(int role) { return role == 0 ? 6 : role == 1 ? 5 : 7; }
-__host__ __device__ constexpr bool meets(int a, int m) { return m >= 0 && m <= 7 && m - a <= 3 && a - m <= 3; }
-__host__ __device__ constexpr int pair_idx(int role, int ab, int m)
-{
-    int idx = 0;
-    for (int mm = m_lo(role); mm <= m_hi(role); ++mm)
-        for (int b = 0; b < NAB; ++b) {
-            if (mm == m && b == ab) return meets(a_blk(role, ab), m) ? idx : -1;
-            if (meets(a_blk(role, b), mm)) ++idx;
-        }
-    return -1;
-}
-constexpr int NP = 11;
-static_assert(pair_idx(0, 1, 6) == NP - 1 && pair_idx(1, 1, 5) == NP - 1 && pair_idx(2, 1, 7) == NP - 1 && pair_idx(3, 1, 7) == NP - 1 &&
-              pair_idx(0, 0, 4) == -1, "11 pairs per role");
-
-template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I0 < I1) {
-        f(std::integral_constant<int, I0>{});
-        static_for<I0 + 1, I1>(f);
-    }
-}
-
-// x - (float)half: one instruction, exact
-__device__ __forceinline__ float resid_lo(unsigned hp, float x)
-{
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
-    return r;
-}
-__device__ __forceinline__ float resid_hi(unsigned hp, float x)
-{
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
-    return r;
-}
-__device__ __forceinline__ unsigned pk_f16(float a, float b)   // v_cvt_pk_f16_f32, round to nearest even
-{
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a, b}, h2));
-}
-
-// One output element as a plain fp32 fma chain over the channels (any finite input): used for outputs whose matrix-core
-// result is non-finite, i.e. an operand did not fit an f16 (or really is inf/nan).
-__device__ __forceinline__ float exact_corr(const Args &p, int n, int y, int x, int tj, int ti)
-{
-    const long HW = (long)p.H * p.W;
-    const int y2 = y + 2 * (tj - DR), x2 = x + 2 * (ti - DR);
-    const float *a = p.in1 + (long)n * p.C * HW + (long)y * p.W + x;
-    const bool inside = y2 >= 0 && y2 < p.H && x2 >= 0 && x2 < p.W;
-    const float *b = p.in2 + (long)n * p.C * HW + (inside ? (long)y2 * p.W + x2 : 0);
-    float s = 0.0f;
-    for (int c = 0; c < p.C; ++c) s = fmaf(a[c * HW], inside ? b[c * HW] : 0.0f, s);
-    return s;
-}
 
 struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
 
