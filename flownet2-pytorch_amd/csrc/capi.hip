@@ -64,11 +64,6 @@ static int corr_forward_impl(const void *in1, const void *in2, void *out, int64_
     // f16x2: two-term f16 split done once per staged value, 3 MFMAs per block product (correlation_f16x2.hip)
     const bool f16x2_ok = corr_f16x2_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2) &&
                           aligned(in1, 16) && aligned(in2, 16) && aligned(out, 16) && (out_batch_stride % 4 == 0);
-    if (debug_variant && algo >= 7000) {   // pair-task kernel (correlation_f16x2_pair.hip)
-        if (!f16x2_ok) return FN2_EUNSUPPORTED;
-        return corr_forward_f16x2_pair(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
-                                       p.out_bs, p.slope, B, C, H, W, algo - 7000, s);
-    }
     if (debug_variant && algo >= 5000) {
         if (!f16x2_ok) return FN2_EUNSUPPORTED;
         return corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
