@@ -87,6 +87,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     const int HL = p.H >> 1;
     const long HW = (long)p.H * p.W;
     const int nsteps = p.C / CK;       // even
+    constexpr bool PADS_FIRST = (VAR & 2048) != 0;   // zero-only tasks before the real ones
 
     // VAR 64 (profiling): s_memtime stamps of wave 0 and wave 8, dumped over the start of the output at the end
     unsigned long long ts[16];
@@ -120,9 +121,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 
     // ---- write-out of the epilogue image (all 16 waves): rows (plane, ti), 16 planes x 21 = 336 rows; a wave instruction
     // stores 4 of them, 16 B per lane
-    const float fC = (float)p.C;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
-    const float rC = 1.0f / fC;
     float *Os = reinterpret_cast<float *>(smem);
     auto store_rows = [&](const Task &tk) {
         if (VAR & 32) return;
@@ -132,51 +131,76 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         asm volatile("" : "+v"(ln));
         const int xg = 4 * (ln & 15);
         constexpr int NR = (16 * D + 63) / 64;   // rows per lane group: 6 (the last one partial)
+        auto row_of = [&](int i) { return wave * 4 + (ln >> 4) + 64 * i; };
+        auto read_row = [&](int row) {
+            const int pl = row / D;
+            const int rr = row < 16 * D ? row : 0;
+            return *reinterpret_cast<const f4 *>(Os + rr * O_RS + ((xg + 4 * (4 * (pl & 3) + (pl >> 2))) & 63));
+        };
+        // 1/C, C and the slope are read from the kernel arguments (SGPRs) where they are used.  As VGPR values they live across
+        // the task loop and get spilled, and a scratch reload waits for vmcnt(0), i.e. for the acknowledgement of every row
+        // store issued before it: a wave then has one store in flight instead of six.
+        auto finish = [&](f4 val) {
+            float r, f, sl;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
+            if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
+            else {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
+                val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f;
+            }
+            if (p.slope != 1.0f) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(sl) : "s"(p.slope));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * sl;
+            }
+            return val;
+        };
+        auto put = [&](int tj, int ti, int y, f4 val) {
+            f4 *dst = reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg);
+            if (VAR & 1024) *dst = val;
+            else __builtin_nontemporal_store(val, dst);   // written once, not read here: keep the inputs in L2 instead
+        };
         f4 vals[NR];
         // all LDS reads first, then the arithmetic and the stores: one LDS latency per task instead of one per row
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int row = wave * 4 + (ln >> 4) + 64 * i;
-            const int pl = row / D;
-            const int rr = row < 16 * D ? row : 0;
-            vals[i] = *reinterpret_cast<const f4 *>(Os + rr * O_RS + ((xg + 4 * (4 * (pl & 3) + (pl >> 2))) & 63));
-        }
+        for (int i = 0; i < NR; ++i) vals[i] = read_row(row_of(i));
+        unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int row = wave * 4 + (ln >> 4) + 64 * i;
+            const int row = row_of(i);
             const int pl = row / D, ti = row - pl * D;
             const int ai = pl >> 2, bi = pl & 3;
             const int tj = 4 * tk.u + bi - ai;
             const int IL = 4 * tk.rg + ai;
             if (row >= 16 * D || tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
-            const int y = 2 * IL + tk.py;
-            f4 val = vals[i];
-            if ((VAR & 127) == 0) {
-                const u4 bits = __builtin_bit_cast(u4, val);
-                const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
-                                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
-                if (bad) {   // an operand did not fit an f16 (or is inf/nan): recompute those outputs in fp32
+            const u4 bits = __builtin_bit_cast(u4, vals[i]);
+            if ((VAR & 127) == 0 &&
+                (((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
+                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u)))
+                bad |= 1u << i;
+            if (!(VAR & 4)) put(tj, ti, 2 * IL + tk.py, finish(vals[i]));
+        }
+        // An operand did not fit an f16 (or is inf/nan): a second pass recomputes exactly those outputs in fp32 and stores the
+        // row again (kept out of the loop above: inlined there, its live state pushes the row values into scratch).
+        if (bad) {
 #pragma unroll 1
-                    for (int e = 0; e < 4; ++e) {
-                        const float ex = exact_corr(p, tk.n, y, xg + e, tj, ti);
-                        const unsigned be = e == 0 ? bits[0] : e == 1 ? bits[1] : e == 2 ? bits[2] : bits[3];
-                        if ((be & 0x7f800000u) == 0x7f800000u) {
-                            val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
-                            val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
-                        }
-                    }
+            for (int i = 0; i < NR; ++i) {
+                if (!(bad >> i & 1)) continue;
+                const int row = row_of(i);
+                const int pl = row / D, ti = row - pl * D;
+                const int ai = pl >> 2, bi = pl & 3;
+                const int tj = 4 * tk.u + bi - ai;
+                const int y = 2 * (4 * tk.rg + ai) + tk.py;
+                f4 val = read_row(row);
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) {
+                    const float cur = e == 0 ? val[0] : e == 1 ? val[1] : e == 2 ? val[2] : val[3];
+                    if ((__builtin_bit_cast(unsigned, cur) & 0x7f800000u) != 0x7f800000u) continue;
+                    const float ex = exact_corr(p, tk.n, y, xg + e, tj, ti);
+                    val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
+                    val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
                 }
-            }
-            if (pow2) val *= rC;
-            else { val[0] /= fC; val[1] /= fC; val[2] /= fC; val[3] /= fC; }
-            if (p.slope != 1.0f) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * p.slope;
-            }
-            if (!(VAR & 4)) {
-                f4 *dst = reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg);
-                if (VAR & 1024) *dst = val;
-                else __builtin_nontemporal_store(val, dst);   // written once, not read here: keep the inputs in L2 instead
+                put(tj, ti, y, finish(val));
             }
         }
     };
@@ -264,6 +288,14 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             issue_loads(L1, chunk(0, 1));
         }
         stamp(1);
+        auto zero_tasks = [&]() {
+            for (int it = n_real; it < n_tasks; ++it) {
+                __syncthreads();
+                store_rows(get_task(it));
+                __syncthreads();
+            }
+        };
+        if (PADS_FIRST) zero_tasks();
         for (int it = 0; it < n_real; ++it) {
             const Task tk = get_task(it);
             const bool has_next = it + 1 < n_real;
@@ -294,11 +326,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             __syncthreads();   // ... and has been read: the buffers are free
             if (it < 2) stamp(6 + 6 * it);
         }
-        for (int it = n_real; it < n_tasks; ++it) {   // zero-only tasks
-            __syncthreads();
-            store_rows(get_task(it));
-            __syncthreads();
-        }
+        if (!PADS_FIRST) zero_tasks();
         stamp(15);
         dump();
         return;
@@ -417,6 +445,11 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         __syncthreads();
         if (it < 2) stamp(6 + 6 * it);
     };
+    if (PADS_FIRST) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99);
+    }
     for (int it = 0; it < n_real; ++it) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -430,9 +463,11 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         }
         epilogue(get_task(it), it);
     }
+    if (!PADS_FIRST) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-    for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99);   // zero-only tasks
+        for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99);   // zero-only tasks
+    }
     stamp(15);
     dump();
 }
@@ -459,6 +494,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     if (!aligned(in1, 16) || !aligned(in2, 16) || !aligned(out, 16) || (out_bs % 4) != 0) return FN2_EALIGN;
     hf::Args a;
     a.in1 = in1; a.in2 = in2; a.out = out; a.out_bs = out_bs; a.slope = slope;
+    a.fC = (float)C; a.rC = 1.0f / (float)C;
     a.B = B; a.C = C; a.H = H; a.W = W;
     a.dbg = variant == 64 ? g_debug_buffer : nullptr;
     const int HL = H / 2, NRG = (HL + 3) / 4;
@@ -488,7 +524,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     const int G = per_stream < 32 ? (int)per_stream : 32;
 #define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3(8u * G), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536)
+        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112)
     default: return FN2_EINVAL;
     }
 #undef FN2_HF

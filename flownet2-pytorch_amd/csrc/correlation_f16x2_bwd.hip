@@ -75,6 +75,7 @@ struct Args {
     int B, C, H, W;        // H even, W % 8 == 0, W <= 64, C % 64 == 0
     int NRG, NCGR;         // row groups per parity, channel groups
     int nflip, flip0;      // 2: both gradients in this launch; 1: only flip0
+    float fC, rC;          // (float)C and 1 / C: kernel arguments so that they are SGPRs (no float SALU on gfx950)
     unsigned long long *dbg;   // profiling variant 64 only: s_memtime stamps (fn2_debug_set_buffer)
 };
 
@@ -166,9 +167,7 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
     const long HW = (long)p.H * p.W;
     const int per_fn = 2 * p.NRG * p.NCGR;                  // tasks per (flip, batch item)
     const int ntasks = p.nflip * p.B * per_fn;
-    const float fC = (float)p.C;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
-    const float rC = 1.0f / fC;
     if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero word(s) of the gathers
     // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and wave 8 (matrix) during the workgroup's first task
     unsigned long long ts[16];
@@ -204,41 +203,65 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
         int ln = lane;
         asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
         const int xg = 4 * (ln & 15);
+        auto row_of = [&](int i) { return wave * 4 + (ln >> 4) + 64 * i; };   // row = c * 4 + ai
+        auto read_row = [&](int row) {
+            const int c = row >> 2, ai = row & 3;
+            return *reinterpret_cast<const f4 *>(Es + row * 64 + ((xg + 8 * ai + 32 * ((c >> 2) & 1)) & 63));
+        };
+        auto scaled = [&](f4 val) {
+            // 1/C and C are read from the kernel arguments (SGPRs) where they are used: as VGPR values they live across the
+            // task loop, get spilled, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store
+            // issued before it, which serialises the four stores of a lane (measured: 7 k instead of 2 k ticks per task)
+            float r, f;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
+            if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
+            else {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
+                val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f;
+            }
+            return val;
+        };
+        auto dst_of = [&](int row) {
+            const int c = row >> 2, ai = row & 3;
+            const int y = 2 * (4 * tk.rg + ai) + tk.py;
+            return reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg);
+        };
         f4 vals[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 4 + (ln >> 4) + 64 * i;   // row = c * 4 + ai
-            const int c = row >> 2, ai = row & 3;
-            vals[i] = *reinterpret_cast<const f4 *>(Es + row * 64 + ((xg + 8 * ai + 32 * ((c >> 2) & 1)) & 63));
-        }
+        for (int i = 0; i < 4; ++i) vals[i] = read_row(row_of(i));
+        unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = wave * 4 + (ln >> 4) + 64 * i;
-            const int c = row >> 2, ai = row & 3;
-            const int IL = 4 * tk.rg + ai;
-            if (IL >= HL || xg >= p.W) continue;
-            const int y = 2 * IL + tk.py;
-            f4 val = vals[i];
-            if ((VAR & 31) == 0) {
-                const u4 bits = __builtin_bit_cast(u4, val);
-                const bool bad = ((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
-                                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u);
-                if (bad) {
+            const int row = row_of(i);
+            if (4 * tk.rg + (row & 3) >= HL || xg >= p.W) continue;
+            const u4 bits = __builtin_bit_cast(u4, vals[i]);
+            if ((VAR & 31) == 0 &&
+                (((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
+                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u)))
+                bad |= 1u << i;
+            if (!(VAR & 4)) *dst_of(row) = scaled(vals[i]);
+        }
+        // Non-finite values (an operand beyond the f16 range): a second pass recomputes exactly those outputs with an fp32 fma
+        // chain and stores the row again.  Kept out of the loop above: inlined there, its live state pushes the row values
+        // into scratch, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store before it.
+        if (bad) {
 #pragma unroll 1
-                    for (int e = 0; e < 4; ++e) {
-                        const float ex = exact_grad(p, tk.flip, tk.n, tk.cg * CG + c, y, xg + e);
-                        const unsigned be = e == 0 ? bits[0] : e == 1 ? bits[1] : e == 2 ? bits[2] : bits[3];
-                        if ((be & 0x7f800000u) == 0x7f800000u) {
-                            val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
-                            val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
-                        }
-                    }
+            for (int i = 0; i < 4; ++i) {
+                if (!(bad >> i & 1)) continue;
+                const int row = row_of(i);
+                const int c = row >> 2, ai = row & 3;
+                const int y = 2 * (4 * tk.rg + ai) + tk.py;
+                f4 val = read_row(row);
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) {
+                    const float cur = e == 0 ? val[0] : e == 1 ? val[1] : e == 2 ? val[2] : val[3];
+                    if ((__builtin_bit_cast(unsigned, cur) & 0x7f800000u) != 0x7f800000u) continue;
+                    const float ex = exact_grad(p, tk.flip, tk.n, tk.cg * CG + c, y, xg + e);
+                    val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
+                    val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
                 }
+                *dst_of(row) = scaled(val);
             }
-            if (pow2) val *= rC;
-            else { val[0] /= fC; val[1] /= fC; val[2] /= fC; val[3] /= fC; }
-            if (!(VAR & 4))
-                *reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg) = val;
         }
     };
 
@@ -582,14 +605,15 @@ int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, f
     a.B = B; a.C = C; a.H = H; a.W = W;
     a.NRG = (H / 2 + 3) / 4; a.NCGR = C / hb::CG;
     a.nflip = 2; a.flip0 = 0;
-    a.dbg = variant == 64 ? static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer()) : nullptr;
+    a.fC = (float)C; a.rC = 1.0f / (float)C;
+    a.dbg = (variant & 64) ? static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer()) : nullptr;
     const long ntasks = 2L * B * 2 * a.NRG * a.NCGR;
     if (ntasks == 0) return FN2_OK;
     if (ntasks > 0x3fffffffL) return FN2_EINVAL;
     const unsigned grid = ntasks < 256 ? (unsigned)ntasks : 256u;   // persistent: one workgroup per CU
 #define FN2_HB(V) case V: hipLaunchKernelGGL((hb::corr_bwd_f16x2<V>), dim3(grid), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31) FN2_HB(64)
+        FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31) FN2_HB(64) FN2_HB(65) FN2_HB(66) FN2_HB(68) FN2_HB(72) FN2_HB(80)
     default: return FN2_EINVAL;
     }
 #undef FN2_HB

@@ -37,6 +37,7 @@ struct Args {
     float *out;
     long out_bs;     // elements between batch items of `out`
     float slope;     // fused LeakyReLU slope (1 = none)
+    float fC, rC;    // (float)C and 1 / C: kernel arguments, i.e. SGPRs (there is no float SALU to derive them on)
     int B, C, H, W;  // H even, W % 8 == 0, W <= 64, C % 64 == 0
     int R_item, P_item;        // tasks per batch item whose B rows meet the image / lie entirely in the padding
     unsigned magic_r, magic_p; // ceil(2^32 / R_item), ceil(2^32 / P_item)

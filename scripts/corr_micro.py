@@ -19,7 +19,10 @@ ap.add_argument("--shape", default="8,256,48,64")
 ap.add_argument("--md", type=int, default=20)
 ap.add_argument("--bwd", default="")
 ap.add_argument("--batch", type=int, default=40)
+ap.add_argument("--lib", default="", help="A/B runs: load this build of libflownet2_hip.so instead of the in-tree one")
 a = ap.parse_args()
+if a.lib:
+    fn2_capi.LIB_PATH = os.path.abspath(a.lib)
 B, C, H, W = (int(v) for v in a.shape.split(","))
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -116,7 +119,7 @@ if a.bwd:
             t0 = int(st[:, :7][st[:, :7] > 0].min())
             for w in range(8):
                 print("   wave", w, [int(v) - t0 if v > 0 else None for v in st[w, :7]])
-        if algo == 6064:   # f16x2 backward timeline of each workgroup's first task
+        if algo >= 6000 and ((algo - 6000) & 64):   # f16x2 backward timeline of each workgroup's first task
             torch.cuda.synchronize()
             st = dbg.cpu().view(256, 2, 16)
             base = st[:, :, 0].min(dim=1, keepdim=True).values.unsqueeze(2)
