@@ -68,7 +68,8 @@ __device__ __forceinline__ Task decode_task(const Args &p, bool real, int k)
 }
 
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no global stores, 8 no operand reads,
-//      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores), 64 s_memtime stamps dumped over the output
+//      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores), 64 s_memtime stamps dumped over the output,
+//      4096 every step loads channel chunk 0 (all loads hit the L2: measured no faster -- misses do not pace the steps)
 //
 // Persistent: the grid is 8 x G workgroups (G <= 32, one per CU); workgroup b belongs to stream b % 8 (= its XCD, so the
 // tasks of one batch item share an L2) and walks a fixed list: every G-th real task of the stream's share, then its share
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         // Channel order.  (Walking the channels backwards in every other task, to start with what is still in L2, measured no
         // gain -- the fabric reads already equal the algorithmic bytes -- and would make the summation order depend on the
         // task's place in the list; profiling switch 512 keeps the experiment.)
-        auto chunk = [&](int it, int s) { return ((VAR & 512) && (it & 1) ? nsteps - 1 - s : s) * CK; };
+        auto chunk = [&](int it, int s) { return (VAR & 4096) ? 0 : ((VAR & 512) && (it & 1) ? nsteps - 1 - s : s) * CK; };
         LoadSet L0, L1;
         if (n_real > 0) {
             set_ctx(get_task(0), true);
@@ -524,7 +525,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     const int G = per_stream < 32 ? (int)per_stream : 32;
 #define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3(8u * G), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112)
+        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112) FN2_HF(4096)
     default: return FN2_EINVAL;
     }
 #undef FN2_HF
