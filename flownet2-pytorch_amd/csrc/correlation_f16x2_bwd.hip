@@ -17,20 +17,25 @@
 // 6 neighbour row blocks u itself (rows 4rg - 10 + 4u .. +3): the sum over neighbours stays in registers, no atomics,
 // deterministic.  Per u:
 //   G image   the 16 (centre row ai, neighbour row bi) combinations x 21 displacement columns x 64 pixels of gO that the
-//             pair (rg, u) touches -- the forward's output tile -- as 32-bit (hi f16 | lo f16) elements [ai][bi][ti][x'] in LDS
-//             (strides padded so that the gather below is conflict-free).  The G operand of (centre block a, neighbour
-//             block pair j) is a GATHER from it: lane (pixel, k group) picks 8 elements with ds_read_b32 (one address
-//             register + immediates; values outside the 21-wide band come from a zero word) and unzips them with 8 v_perm;
-//             gathered once per u into registers and reused for the 4 channel tiles.
+//             pair (rg, u) touches -- the forward's output tile -- as the raw fp32 rows [ai][bi][ti][x] in LDS, copied by
+//             LDS-DMA (buffer_load_dword ... lds: one 256-byte row per instruction, no VGPRs, no VALU, no ds_write; rows
+//             outside the image / the displacement range arrive as zeros from the buffer range check); strides padded so
+//             that the gather below is conflict-free.  The G operand of (centre block a, neighbour block pair j) is a
+//             GATHER from it: lane (pixel, k group) picks 8 values with ds_read_b32 (one address register + immediates;
+//             values outside the 21-wide band come from a zero word) and splits them into the hi and lo f16 fragments in
+//             registers (an image element is gathered ~1.1 times per u, so splitting here costs what splitting while
+//             staging did -- but the image no longer passes through the staging waves' registers and the LDS store path);
+//             gathered once per u and reused for the 4 channel tiles.
 //   X tile    4 neighbour rows x 64 pixels x 32 channels per chunk, the LDS image of the forward kernel (8-byte chunks of
 //             4 lattice columns, [term][parity][channel][column block][row]): the X operand of (channel tile, block pair)
 //             is two plain ds_read_b128 (hi, lo) -- the neighbour pixels of one channel are contiguous.
 // Waves are specialised as in the forward: waves 0-7 stage (buffer loads whose range check returns zeros outside the
 // image / the displacement range, split, LDS writes), waves 8-15 gather and run the MFMAs: wave w takes x parity w&1
 // and the centre column blocks of role w>>1 ({0,3},{1,2},{4,7},{5,6}: 6 (block, pair) products each) x 4 channel tiles.
-// Two barriers per u: [gather the 6 G operands | write both X chunks] [72 MFMAs | write G(u+1)].
-// Epilogue: accumulators -> LDS [channel][row][x] (16-byte slots rotated) -> rows of 256 B, scaled by 1/C; outputs that
-// came out non-finite (an operand did not fit an f16) are recomputed in plain fp32.
+// Two barriers per u: [gather the 6 G operands | write both X chunks] [72 MFMAs | DMA of G(u+1)].
+// Epilogue: accumulators -> LDS [channel][row][x] (16-byte slots rotated; over the X buffers, so that the G image of the
+// workgroup's next task is already being filled) -> rows of 256 B, scaled by 1/C; outputs that came out non-finite (an
+// operand did not fit an f16) are recomputed in plain fp32.
 #include <type_traits>
 
 #include "corr_params.h"
@@ -52,21 +57,20 @@ constexpr int CG = 64, NCT = CG / 16;             // channels per task, channel 
 constexpr int CK = 32;                            // channels per X chunk (2 tiles)
 // X chunk image (bytes), as in correlation_f16x2.hip
 constexpr int CHS = 288, PARS = CK * CHS, XTERM = 2 * PARS, XBUF = 2 * XTERM;   // 9216, 18432, 36864
-// G image (bytes): [ai][bi][ti][x'] with 32-bit elements (hi f16 | lo f16 << 16) and x' = 32 * x parity + lattice column.
-// Strides are padded so that the 32 lanes of a gather (aj, ai, bi parity) hit 32 distinct banks: a lane's aj moves the
-// column for FLIP 0 but the displacement row for FLIP 1, so the row stride is 256 B for FLIP 0 and 260 B for FLIP 1;
-// bi stride = 32 mod 64 (two bi = 16 banks), ai stride = 16 mod 128 (4 banks)
-template <int FLIP> struct GL {
-    static constexpr int TI = FLIP ? 260 : 256;
-    static constexpr int BI = FLIP ? D * 260 + 12 : D * 256 + 32;   // 5472 / 5408
-    static constexpr int AI = 4 * BI + 16;                          // 21904 / 21648
-    static constexpr int IMG = 4 * AI;                              // 87616 / 86592
+// G image (bytes): [ai][bi][ti][x], fp32, x in natural pixel order.  Strides are padded so that the 32 lanes of a gather
+// (aj, ai, bi parity) hit 32 distinct banks: a lane's aj moves the displacement row by one (and, FLIP 0, the column by two
+// pixels): row stride 260 B = 1 bank (+ 8 B = 2 banks: 4 aj mod 128 either way), bi stride = 32 mod 64 (two bi = 16 banks),
+// ai stride = 16 mod 128 (4 banks)
+struct GL {
+    static constexpr int TI = 256;
+    static constexpr int BI = D * 256 + 32;    // 5408
+    static constexpr int AI = 4 * BI + 16;     // 21648
+    static constexpr int IMG = 4 * AI;         // 86592
 };
-static_assert(GL<0>::BI % 64 == 32 && GL<1>::BI % 64 == 32 && GL<0>::AI % 128 == 16 && GL<1>::AI % 128 == 16, "gather bank pattern");
-constexpr int GIMG = GL<1>::IMG;
+constexpr int GIMG = GL::IMG;
 constexpr int X_OFS = GIMG, ZERO_OFS = X_OFS + 2 * XBUF, LDS_BYTES = ZERO_OFS + 64;                          // 87616, 161344, 161408
-constexpr int E_BYTES = CG * 4 * 64 * 4;          // epilogue image [64 channels][4 rows][64 x] floats, aliases the G image
-static_assert(E_BYTES <= GIMG && LDS_BYTES <= 163840, "LDS budget");
+constexpr int E_BYTES = CG * 4 * 64 * 4;          // epilogue image [64 channels][4 rows][64 x] floats, aliases the X buffers
+static_assert(E_BYTES <= 2 * XBUF && LDS_BYTES <= 163840, "LDS budget");
 
 struct Args {
     const float *nbr[2];   // [0] = in2 (neighbours for gradInput1), [1] = in1 (for gradInput2)
@@ -149,34 +153,35 @@ __device__ __forceinline__ float exact_grad(const Args &p, int flip, int n, int 
     return s;
 }
 
-struct XSet { u4 v[2][2]; };       // one X chunk of one lane: [slot][half] x 16 B (8 pixels)
-constexpr int NGI = 6;             // G items (8 pixels) per staging lane: 16 planes x 21 x 8 = 2688 = 5.25 x 512
+constexpr int NSW = 4, NWAVES = NSW + 8;   // staging waves, waves per workgroup (3 per SIMD: 168 VGPRs each)
+constexpr int XK = 32 / (2 * NSW);          // X items per chunk (32 channels) and staging lane
+struct XSet { u4 v[XK][2]; };      // one X chunk of one lane: [slot][half] x 16 B (8 pixels)
 
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no stores, 8 no gathers / operand reads,
 //      16 no split / LDS staging writes
 template <int VAR>
-__global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
+__global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_stage = wave < 8;
-    const int w8 = wave & 7;
+    const bool is_stage = wave < NSW;
+    const int w8 = is_stage ? wave : wave - NSW;   // staging wave 0 .. NSW-1 / matrix wave 0 .. 7
     const int HL = p.H >> 1;
     const long HW = (long)p.H * p.W;
     const int per_fn = 2 * p.NRG * p.NCGR;                  // tasks per (flip, batch item)
     const int ntasks = p.nflip * p.B * per_fn;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero word(s) of the gathers
-    // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and wave 8 (matrix) during the workgroup's first task
+    // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and the first matrix wave during the workgroup's first task
     unsigned long long ts[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ts[i] = 0;
     auto stamp = [&](int i) __attribute__((always_inline)) { if (VAR & 64) ts[i] = __builtin_amdgcn_s_memtime(); };
     auto dump = [&]() __attribute__((always_inline)) {
-        if ((VAR & 64) && p.dbg && lane == 0 && (wave == 0 || wave == 8)) {
-            unsigned long long *d = p.dbg + (blockIdx.x * 2 + (wave >> 3)) * 16;
+        if ((VAR & 64) && p.dbg && lane == 0 && (wave == 0 || wave == NSW)) {
+            unsigned long long *d = p.dbg + (blockIdx.x * 2 + (wave ? 1 : 0)) * 16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) d[i] = ts[i];
         }
@@ -198,12 +203,13 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
     };
 
     // ---- write-out of the epilogue image (all 16 waves): 256 rows (channel, centre row) of 64 floats, 4 rows per instruction
-    float *Es = reinterpret_cast<float *>(smem);
+    float *Es = reinterpret_cast<float *>(smem + X_OFS);
     auto store_rows = [&](const Task &tk) {
         int ln = lane;
         asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
         const int xg = 4 * (ln & 15);
-        auto row_of = [&](int i) { return wave * 4 + (ln >> 4) + 64 * i; };   // row = c * 4 + ai
+        constexpr int NRI = (256 + 4 * NWAVES - 1) / (4 * NWAVES);   // row groups per lane
+        auto row_of = [&](int i) { return wave * 4 + (ln >> 4) + 4 * NWAVES * i; };   // row = c * 4 + ai
         auto read_row = [&](int row) {
             const int c = row >> 2, ai = row & 3;
             return *reinterpret_cast<const f4 *>(Es + row * 64 + ((xg + 8 * ai + 32 * ((c >> 2) & 1)) & 63));
@@ -226,14 +232,14 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
             const int y = 2 * (4 * tk.rg + ai) + tk.py;
             return reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg);
         };
-        f4 vals[4];
+        f4 vals[NRI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vals[i] = read_row(row_of(i));
+        for (int i = 0; i < NRI; ++i) vals[i] = read_row(row_of(i) & 255);
         unsigned bad = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NRI; ++i) {
             const int row = row_of(i);
-            if (4 * tk.rg + (row & 3) >= HL || xg >= p.W) continue;
+            if (row >= 256 || 4 * tk.rg + (row & 3) >= HL || xg >= p.W) continue;
             const u4 bits = __builtin_bit_cast(u4, vals[i]);
             if ((VAR & 31) == 0 &&
                 (((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
         // into scratch, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store before it.
         if (bad) {
 #pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NRI; ++i) {
                 if (!(bad >> i & 1)) continue;
                 const int row = row_of(i);
                 const int c = row >> 2, ai = row & 3;
@@ -267,135 +273,118 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
 
     if (is_stage) {
         // ================= staging waves =================
-        // G items: 8 pixels of one gO row each (two 16-byte loads).  Item k (0 .. 5) of a lane: plane = 2 w8 + (lane >> 5),
-        // ti = 4k + ((lane >> 3) & 3), piece = lane & 7 -- LDS offset and gO offset are linear in k (immediates / scalar
-        // offsets); only ti <= 20 exists (k = 5: the first quarter)
+        // G rows: staging wave w copies the 21 rows of planes 2w and 2w + 1 (plane = 4 ai + bi), one 256-byte row per DMA
+        // instruction (lane = pixel x); LDS address and gO offset of a row are scalars.
         // X items (as the forward's tiles): slot k covers channels 16k .. 16k+15 of the chunk
         const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
         const int s_row = (lane >> 2) & 3;
-        const int s_ch = 2 * w8 + (lane >> 5);
+        const int s_ch = 2 * w8 + (lane >> 5);            // + 2 NSW k: slot k of a chunk
         const int s_x = 8 * s_piece;
         const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;
         const unsigned xbytes = (unsigned)(p.C * HW * 4), gbytes = (unsigned)(D * D * HW * 4);
 
-        for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
-            const Task tk = get_task(t);
-            const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
+        // G(u) of task tk -> LDS.  FLIP 0: tj = 4u + bi - ai, gO row = centre row ai.  FLIP 1: tj = 20 - 4u - bi + ai, gO row =
+        // neighbour row bi.  Rows that do not exist get an out-of-range lane offset: the DMA writes zeros.
+        auto g_dma = [&](const Task &tk, int u) {
+            if (VAR & 2) return;
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const int g_plane = 2 * w8 + (ln >> 5), g_ai = g_plane >> 2, g_bi = g_plane & 3;
-            const int g_tiq = (ln >> 3) & 3, g_pc = ln & 7;
-            const int g_ti = tk.flip ? GL<1>::TI : GL<0>::TI;                               // row stride of this task's image
-            const int g_ofs = tk.flip ? g_ai * GL<1>::AI + g_bi * GL<1>::BI + g_tiq * GL<1>::TI + g_pc * 16
-                                      : g_ai * GL<0>::AI + g_bi * GL<0>::BI + g_tiq * GL<0>::TI + g_pc * 16;   // + k * 4 * row stride; x parity 1: + 128
-            // FLIP 0: tj = 4u + bi - ai, gO row = centre row ai.   FLIP 1: tj = 20 - 4u - bi + ai, gO row = neighbour row bi
-            const int g_tj0 = tk.flip ? 20 - g_bi + g_ai : g_bi - g_ai;                  // tj at u = 0; +-4 per u
-            const int g_il0 = tk.flip ? 4 * tk.rg - DR + g_bi : 4 * tk.rg + g_ai;         // gO lattice row at u = 0; +4 per u for FLIP 1
-            const int g_base = ((g_tj0 * D + g_tiq) * p.H + 2 * g_il0 + tk.py) * p.W + 8 * g_pc;   // element offset at u = 0, k = 0
-            const int g_du = tk.flip ? (-4 * D * p.H + 8) * p.W : 4 * D * p.H * p.W;      // element offset step per u
-            const int g_dk = 4 * p.H * p.W;                                               // ... per k (four ti planes)
-            u4 gv[NGI][2];
-            auto g_issue = [&](int u) {
-                const int tj = tk.flip ? g_tj0 - 4 * u : g_tj0 + 4 * u;
-                const int il = tk.flip ? g_il0 + 4 * u : g_il0;
-                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL && 8 * g_pc < p.W;
-                const unsigned vo = ok ? (unsigned)((g_base + u * g_du) * 4) : 0x80000000u;
-                const unsigned vo_last = g_tiq ? 0x80000000u : vo;                        // k = 5: ti = 20 .. 23
+            const unsigned vin = 4 * (ln & 15) < p.W ? (unsigned)((ln & 15) * 16) : 0x80000000u;
+            const int r4 = ln >> 4;                       // row of the 4-row group this lane copies
 #pragma unroll
-                for (int k = 0; k < NGI; ++k) {
-                    const unsigned v = k == NGI - 1 ? vo_last : vo;
-                    if (VAR & 2) { gv[k][0] = (u4)(0x3c000000u + lane); gv[k][1] = gv[k][0]; continue; }
-                    gv[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)v, k * g_dk * 4, 0);
-                    gv[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)(v + 16), k * g_dk * 4, 0);
+            for (int pl2 = 0; pl2 < 16 / NSW; ++pl2) {
+                const int plane = (16 / NSW) * w8 + pl2, ai = plane >> 2, bi = plane & 3;
+                const int tj = tk.flip ? 20 - 4 * u - bi + ai : 4 * u + bi - ai;
+                const int il = tk.flip ? 4 * tk.rg - DR + 4 * u + bi : 4 * tk.rg + ai;
+                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL;
+                const int g0 = ok ? ((tj * D) * p.H + 2 * il + tk.py) * p.W * 4 : 0;   // byte offset of row ti = 0
+                const int l0 = ai * GL::AI + bi * GL::BI;
+                const unsigned vo = ok ? vin + (unsigned)(r4 * (int)(HW * 4)) : 0x80000000u;
+#pragma unroll
+                for (int tg = 0; tg < 6; ++tg) {
+                    const unsigned v = (tg == 5 && r4 > 0) ? 0x80000000u : vo;     // rows 21 .. 23 do not exist
+                    if (tg < 5 || r4 == 0)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (FN2_LDS(void) *)(smem + l0 + tg * 4 * GL::TI), 16, (int)v, g0 + tg * 4 * (int)(HW * 4), 0, 0);
                 }
-            };
-            // one value -> (f16(x) | f16(x - f16(x)) << 16)
-            auto word = [&](unsigned hpair, bool hi_half, float x) -> unsigned {
-                const float r = hi_half ? resid_hi(hpair, x) : resid_lo(hpair, x);
-                return pk_f16(x, r);
-            };
-            auto g_write = [&]() {
+            }
+        };
+        // X chunk (u, ch): neighbour rows 4rg - 10 + 4u .. +3, channels cg*64 + 32*ch .. +31
+        auto x_issue = [&](XSet &L, const Task &tk, int u, int ch) {
+            const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
+            const int il = 4 * tk.rg - DR + 4 * u + s_row;
+            const bool ok = il >= 0 && il < HL && s_x < p.W;
+            const unsigned vo = ok ? (unsigned)((s_ch * HW + (long)(2 * il + tk.py) * p.W + s_x) * 4) : 0x80000000u;
 #pragma unroll
-                for (int k = 0; k < NGI; ++k) {
-                    if (VAR & 16) { asm volatile("" ::"v"(gv[k][0]), "v"(gv[k][1])); continue; }
-                    const f4 x0 = __builtin_bit_cast(f4, gv[k][0]), x1 = __builtin_bit_cast(f4, gv[k][1]);
-                    if (k < NGI - 1 || !g_tiq) {
+            for (int k = 0; k < XK; ++k) {
+                const int soff = (int)((tk.cg * CG + ch * CK + 2 * NSW * k) * HW * 4);
+                if (VAR & 2) { L.v[k][0] = (u4)(0x3c000000u + lane); L.v[k][1] = L.v[k][0]; continue; }
+                L.v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, soff, 0);
+                L.v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(vo + 16), soff, 0);
+            }
+        };
+        auto x_write = [&](const XSet &L, char *buf) {
 #pragma unroll
-                        for (int par = 0; par < 2; ++par) {
-                            const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
-                            const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
-                            const u4 w = {word(h01, false, e0), word(h01, true, e1), word(h23, false, e2), word(h23, true, e3)};
-                            *(FN2_LDS(u4) *)(smem + g_ofs + k * 4 * g_ti + par * 128) = w;
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < XK; ++k) {
+                if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); continue; }
+                const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]);
+                char *dst = buf + w_ofs + k * 2 * NSW * CHS;
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
+                    const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
+                    const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
+                    const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+                    *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
+                    *(FN2_LDS(u2) *)(dst + XTERM + par * PARS) = (u2){l01, l23};
                 }
-            };
-            // X chunk (u, ch): neighbour rows 4rg - 10 + 4u .. +3, channels cg*64 + 32*ch .. +31
-            auto x_issue = [&](XSet &L, int u, int ch) {
-                const int il = 4 * tk.rg - DR + 4 * u + s_row;
-                const bool ok = il >= 0 && il < HL && s_x < p.W;
-                const unsigned vo = ok ? (unsigned)((s_ch * HW + (long)(2 * il + tk.py) * p.W + s_x) * 4) : 0x80000000u;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int soff = (int)((tk.cg * CG + ch * CK + 16 * k) * HW * 4);
-                    if (VAR & 2) { L.v[k][0] = (u4)(0x3c000000u + lane); L.v[k][1] = L.v[k][0]; continue; }
-                    L.v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, soff, 0);
-                    L.v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(vo + 16), soff, 0);
-                }
-            };
-            auto x_write = [&](const XSet &L, char *buf) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); continue; }
-                    const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]);
-                    char *dst = buf + w_ofs + k * 16 * CHS;
-#pragma unroll
-                    for (int par = 0; par < 2; ++par) {
-                        const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
-                        const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
-                        const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
-                        const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
-                        *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
-                        *(FN2_LDS(u2) *)(dst + XTERM + par * PARS) = (u2){l01, l23};
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // the DMA's LDS writes are complete when its vector-memory counter has drained
+        auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-            // prologue: G(0) into LDS, both X chunks of u = 0 and G(1) in flight
-            XSet X0, X1;
-            g_issue(0);
-            x_issue(X0, 0, 0);
-            x_issue(X1, 0, 1);
+        // Invariant at the top of a task: its G(0) is in LDS (or landing), both X chunks of u = 0 are in flight in X0, X1.
+        XSet X0, X1;
+        int t = (int)xcd_remap(blockIdx.x, gridDim.x);
+        if (t < ntasks) {
+            const Task tk = get_task(t);
+            x_issue(X0, tk, 0, 0);
+            x_issue(X1, tk, 0, 1);
+            g_dma(tk, 0);
+            stamp(1);
+            dma_wait();
+            stamp(2);
+        }
+        __syncthreads();                                       // (A) G(0) complete
+        stamp(3);
+        for (; t < ntasks; t += gridDim.x) {
+            const Task tk = get_task(t);
+            const bool has_next = t + (int)gridDim.x < ntasks;
+            const Task tn = get_task(has_next ? t + (int)gridDim.x : t);
             const bool first = t < (int)gridDim.x;
-            if (first) stamp(1);
-            g_write();
-            g_issue(1);
-            if (first) stamp(2);
-            __syncthreads();                                   // (A) G(0) complete
-            if (first) stamp(3);
             for (int u = 0; u < NU; ++u) {
-                // phase 1 (the matrix waves gather the G operands of u): both X chunks of u
+                // phase 1 (the matrix waves gather the G operands of u): both X chunks of u; the loads of the next X chunks
                 x_write(X0, smem + X_OFS);
                 x_write(X1, smem + X_OFS + XBUF);
-                if (u + 1 < NU) { x_issue(X0, u + 1, 0); x_issue(X1, u + 1, 1); }
+                if (u + 1 < NU) { x_issue(X0, tk, u + 1, 0); x_issue(X1, tk, u + 1, 1); }
+                else if (has_next) { x_issue(X0, tn, 0, 0); x_issue(X1, tn, 0, 1); }
                 if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 if (first && u < 2) stamp(5 + 4 * u);
-                // phase 2 (all MFMAs of u): G(u+1)
-                if (u + 1 < NU) g_write();
-                if (u + 2 < NU) g_issue(u + 2);
+                // phase 2 (all MFMAs of u): G(u+1), or G(0) of the next task, by DMA
+                if (u + 1 < NU) g_dma(tk, u + 1);
+                else if (has_next) g_dma(tn, 0);
+                dma_wait();
                 if (first && u < 2) stamp(6 + 4 * u);
-                __syncthreads();                               // (A') the X buffers are free, G(u+1) complete
+                __syncthreads();                               // (A') the X buffers are free, the next G image complete
                 if (first && u < 2) stamp(7 + 4 * u);
             }
             if (first) stamp(12);
-            __syncthreads();                                   // epilogue image complete
+            __syncthreads();                                   // epilogue image (over the X buffers) complete
             if (first) stamp(13);
             store_rows(tk);
-            __syncthreads();                                   // image read: LDS free for the next task
+            __syncthreads();                                   // image read: the X buffers are free for the next task
             if (first) stamp(14);
         }
         stamp(15);
@@ -426,17 +415,19 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
 
         // Gather of the G operands.  Slot s of k group g = neighbour (block m = 2j + blk, row bi = 2gg + (s>>2), column bj = s&3)
         // with blk = g>>1, gg = g&1, dm = m - a:
-        //   FLIP 0: ti = 4 dm + bj - aj + 10, x' = 32 par + 4a + aj      FLIP 1: ti = 10 - 4 dm - bj + aj, x' = 32 par + 4m + bj
-        // byte offset = ai AI + bi BI + ti TI + 4 x' = lane part + slot part + (a, j) part; the lane part is recomputed in
-        // every call from an opaque copy of the lane id (hoisted out of the u loop it would be 48 live addresses).
+        //   FLIP 0: ti = 4 dm + bj - aj + 10, x = 2 (4a + aj) + par      FLIP 1: ti = 10 - 4 dm - bj + aj, x = 2 (4m + bj) + par
+        // byte offset = ai AI + bi BI + ti TI + 4 x = lane part + slot part + (a, j) part; the lane part is recomputed in
+        // every call from an opaque copy of the lane id (hoisted out of the u loop it would be 48 live addresses).  The slot
+        // part is kept non-negative (ds_read immediates): FLIP 1 walks bj downwards from 3.
         auto gather = [&](auto role_c) {
             constexpr int R = decltype(role_c)::value;
-            typedef GL<FLIP> L;
+            typedef GL L;
+            constexpr int SB = L::TI - 8;                                         // FLIP 1: one column less = one displacement row more
             int l2 = lane;
             asm volatile("" : "+v"(l2));
             const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = l2 >> 5, gg = (l2 >> 4) & 1;
-            const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * (L::TI - 4) + 16 * blk + 128 * xpar
-                                   : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 4 * aj + 128 * xpar;
+            const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * SB + 32 * blk + 4 * xpar
+                                   : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 8 * aj + 4 * xpar;
             const int t0 = FLIP ? DR - 4 * blk + aj : DR + 4 * blk - aj;        // ti = t0 -+ 4 (2j - a) -+ bj
             static_for<0, 2>([&](auto abc) {
                 constexpr int ab = decltype(abc)::value;
@@ -446,27 +437,28 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
                     constexpr int fi = frag_idx(R, ab, j);
                     if constexpr (fi >= 0) {
                         constexpr int dj = 2 * j - a;                             // dm = dj + blk
-                        constexpr int pconst = FLIP ? -4 * dj * L::TI + 32 * j : 4 * dj * L::TI + 16 * a;
+                        constexpr int pconst = FLIP ? -4 * dj * L::TI + 64 * j : 4 * dj * L::TI + 32 * a;
                         constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
                         const int fbase = lbase + pconst;
                         const int tb = FLIP ? t0 - 4 * dj : t0 + 4 * dj;          // ti of bj = 0
-                        unsigned w[8];
+                        float w[8];
                         static_for<0, 8>([&](auto sc) {
                             constexpr int s = decltype(sc)::value;
                             constexpr int bjs = s & 3, bis = s >> 2;
-                            constexpr int sconst = FLIP ? bis * L::BI + (3 - bjs) * (L::TI - 4) : bis * L::BI + bjs * L::TI;
+                            constexpr int sconst = FLIP ? bis * L::BI + (3 - bjs) * SB : bis * L::BI + bjs * L::TI;
                             int ofs = fbase + sconst;
                             if constexpr (check) {
                                 const int ti = FLIP ? tb - bjs : tb + bjs;
                                 ofs = (ti >= 0 && ti < D) ? ofs : ZERO_OFS;
                             }
-                            w[s] = (VAR & 8) ? 0x3c00u : *reinterpret_cast<const unsigned *>(smem + ofs);
+                            w[s] = (VAR & 8) ? 1.0f : *reinterpret_cast<const float *>(smem + ofs);
                         });
-                        u4 vh, vl;   // (hi, hi) and (lo, lo) pairs of consecutive slots
+                        // two-term split in registers: slots (2q, 2q+1) -> one packed pair of each fragment
+                        u4 vh, vl;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            vh[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u);
-                            vl[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u);
+                            vh[q] = pk_f16(w[2 * q], w[2 * q + 1]);
+                            vl[q] = pk_f16(resid_lo(vh[q], w[2 * q]), resid_hi(vh[q], w[2 * q + 1]));
                         }
                         gh[fi] = __builtin_bit_cast(h8, vh);
                         gl[fi] = __builtin_bit_cast(h8, vl);
@@ -531,8 +523,6 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
             }
         };
 
-        __syncthreads();                                       // (A) G(0) complete
-        if (first) stamp(3);
         for (int u = 0; u < NU; ++u) {
             gather_d();                                        // phase 1
             if (first && u < 2) stamp(4 + 4 * u);
@@ -574,6 +564,8 @@ __global__ __launch_bounds__(1024, 4) void corr_bwd_f16x2(Args p)
         __syncthreads();
         if (first) stamp(14);
     };
+    __syncthreads();                                           // (A) G(0) of the first task complete
+    stamp(3);
     for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
         const Task tk = get_task(t);
         const bool first = t < (int)gridDim.x;
@@ -611,7 +603,7 @@ int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, f
     if (ntasks == 0) return FN2_OK;
     if (ntasks > 0x3fffffffL) return FN2_EINVAL;
     const unsigned grid = ntasks < 256 ? (unsigned)ntasks : 256u;   // persistent: one workgroup per CU
-#define FN2_HB(V) case V: hipLaunchKernelGGL((hb::corr_bwd_f16x2<V>), dim3(grid), dim3(1024), 0, s, a); return launch_status();
+#define FN2_HB(V) case V: hipLaunchKernelGGL((hb::corr_bwd_f16x2<V>), dim3(grid), dim3(hb::NWAVES * 64), 0, s, a); return launch_status();
     switch (variant) {
         FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31) FN2_HB(64) FN2_HB(65) FN2_HB(66) FN2_HB(68) FN2_HB(72) FN2_HB(80)
     default: return FN2_EINVAL;
