@@ -29,9 +29,11 @@
 //   X tile    4 neighbour rows x 64 pixels x 32 channels per chunk, the LDS image of the forward kernel (8-byte chunks of
 //             4 lattice columns, [term][parity][channel][column block][row]): the X operand of (channel tile, block pair)
 //             is two plain ds_read_b128 (hi, lo) -- the neighbour pixels of one channel are contiguous.
-// Waves are specialised as in the forward: waves 0-7 stage (buffer loads whose range check returns zeros outside the
-// image / the displacement range, split, LDS writes), waves 8-15 gather and run the MFMAs: wave w takes x parity w&1
-// and the centre column blocks of role w>>1 ({0,3},{1,2},{4,7},{5,6}: 6 (block, pair) products each) x 4 channel tiles.
+// 12 waves per workgroup, 3 per SIMD (168-register budget: 158 used, no scratch), specialised: waves 0-3 stage (the G DMA,
+// buffer loads of X whose range check returns zeros outside the image, X split, LDS writes), waves 4-11 gather and run the
+// MFMAs: matrix wave w takes x parity w&1 and the centre column blocks of role w>>1 ({0,3},{1,2},{4,7},{5,6}: 6 (block, pair)
+// products each) x 4 channel tiles.  MFMA and VALU instructions of one SIMD do not overlap (scripts/ubench/mfma_valu_overlap),
+// so a u costs the SIMD 144 MFMAs + ~650 VALU instructions: the kernel runs within ~25 % of that bound.
 // Two barriers per u: [gather the 6 G operands | write both X chunks] [72 MFMAs | DMA of G(u+1)].
 // Epilogue: accumulators -> LDS [channel][row][x] (16-byte slots rotated; over the X buffers, so that the G image of the
 // workgroup's next task is already being filled) -> rows of 256 B, scaled by 1/C; outputs that came out non-finite (an
@@ -57,18 +59,24 @@ constexpr int CG = 64, NCT = CG / 16;             // channels per task, channel 
 constexpr int CK = 32;                            // channels per X chunk (2 tiles)
 // X chunk image (bytes), as in correlation_f16x2.hip
 constexpr int CHS = 288, PARS = CK * CHS, XTERM = 2 * PARS, XBUF = 2 * XTERM;   // 9216, 18432, 36864
-// G image (bytes): [ai][bi][ti][x], fp32, x in natural pixel order.  Strides are padded so that the 32 lanes of a gather
-// (aj, ai, bi parity) hit 32 distinct banks: a lane's aj moves the displacement row by one (and, FLIP 0, the column by two
-// pixels): row stride 260 B = 1 bank (+ 8 B = 2 banks: 4 aj mod 128 either way), bi stride = 32 mod 64 (two bi = 16 banks),
-// ai stride = 16 mod 128 (4 banks)
-struct GL {
-    static constexpr int TI = 256;
-    static constexpr int BI = D * 256 + 32;    // 5408
-    static constexpr int AI = 4 * BI + 16;     // 21648
-    static constexpr int IMG = 4 * AI;         // 86592
+// G image (bytes): [ai][ti][bi][x], fp32, x in natural pixel order: the four neighbour rows bi of one (ai, ti) are one
+// contiguous KB -- one 16-byte-per-lane DMA instruction -- and the strides of ti and ai are free (the DMA's LDS base only needs
+// 4-byte alignment: scripts/ubench/dma_align_probe.hip).  They are chosen so that the 32 lanes of a gather instruction -- 16
+// centre pixels (ai, aj) x the two neighbour column blocks of a pair (k groups g = 0, 1: blk = g & 1) -- hit 32 distinct banks:
+//   FLIP 0 (a lane's aj moves the displacement row down by one and the pixel by two): 8-byte gathers (pixel pair, the
+//           wave's parity is picked in registers), units of 8 B mod 32: aj -> -3, ai -> +4, blk -> +16
+//   FLIP 1 (aj moves the displacement row up by one, the pixel is the k slot's): 4-byte gathers, banks mod 32: aj -> +1, ai -> +8,
+//           blk -> +4
+template <int FLIP> struct GL {
+    static constexpr int BI = 256;
+    static constexpr int TI = FLIP ? 1024 + 4 : 1024 + 32;
+    static constexpr int AI = FLIP ? D * TI + 76 : D * TI + 128;      // 21664 / 22304
+    static constexpr int IMG = 3 * AI + D * TI;                         // 86580 / 89088
 };
-constexpr int GIMG = GL::IMG;
-constexpr int X_OFS = GIMG, ZERO_OFS = X_OFS + 2 * XBUF, LDS_BYTES = ZERO_OFS + 64;                          // 87616, 161344, 161408
+static_assert(GL<0>::TI % 256 == 32 && GL<0>::AI % 256 == 32 && GL<1>::TI % 128 == 4 && GL<1>::AI % 128 == 32, "gather bank pattern");
+constexpr int GIMG = GL<0>::IMG;
+static_assert(GL<1>::IMG <= GIMG && GIMG % 16 == 0, "G image");
+constexpr int X_OFS = GIMG, ZERO_OFS = X_OFS + 2 * XBUF, LDS_BYTES = ZERO_OFS + 64;                          // 89088, 162816, 162880
 constexpr int E_BYTES = CG * 4 * 64 * 4;          // epilogue image [64 channels][4 rows][64 x] floats, aliases the X buffers
 static_assert(E_BYTES <= 2 * XBUF && LDS_BYTES <= 163840, "LDS budget");
 
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int per_fn = 2 * p.NRG * p.NCGR;                  // tasks per (flip, batch item)
     const int ntasks = p.nflip * p.B * per_fn;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
-    if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero word(s) of the gathers
+    if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero words of the gathers (8-byte reads: FLIP 0)
     // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and the first matrix wave during the workgroup's first task
     unsigned long long ts[16];
 #pragma unroll
@@ -280,77 +288,75 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         const int s_row = (lane >> 2) & 3;
         const int s_ch = 2 * w8 + (lane >> 5);            // + 2 NSW k: slot k of a chunk
         const int s_x = 8 * s_piece;
-        const int w_ofs = s_ch * CHS + s_piece * 32 + s_row * 8;
+        // within a channel: 16-byte unit 4 j + 2 gg + blk (block pair j, rows 2 gg .. 2 gg + 1 of block 2 j + blk): the four k groups
+        // g = 2 gg + blk of an X operand are consecutive units
+        const int w_ofs = s_ch * CHS + (s_piece >> 1) * 64 + (s_piece & 1) * 16 + (s_row >> 1) * 32 + (s_row & 1) * 8;
         const unsigned xbytes = (unsigned)(p.C * HW * 4), gbytes = (unsigned)(D * D * HW * 4);
 
-        // G(u) of task tk -> LDS.  FLIP 0: tj = 4u + bi - ai, gO row = centre row ai.  FLIP 1: tj = 20 - 4u - bi + ai, gO row =
-        // neighbour row bi.  Rows that do not exist get an out-of-range lane offset: the DMA writes zeros.
+        // G(u) of task tk -> LDS: staging wave w copies centre row ai = w, one DMA instruction per displacement column ti (lane =
+        // (neighbour row bi, 16-byte piece)).  FLIP 0: tj = 4u + bi - ai, gO row = centre row ai.  FLIP 1: tj = 20 - 4u - bi + ai,
+        // gO row = neighbour row bi.  Rows that do not exist get an out-of-range lane offset: the DMA writes zeros.
         auto g_dma = [&](const Task &tk, int u) {
             if (VAR & 2) return;
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const unsigned vin = 4 * (ln & 15) < p.W ? (unsigned)((ln & 15) * 16) : 0x80000000u;
-            const int r4 = ln >> 4;                       // row of the 4-row group this lane copies
+            const int bi = ln >> 4, pc = ln & 15;
 #pragma unroll
-            for (int pl2 = 0; pl2 < 16 / NSW; ++pl2) {
-                const int plane = (16 / NSW) * w8 + pl2, ai = plane >> 2, bi = plane & 3;
+            for (int k = 0; k < 4 / NSW; ++k) {
+                const int ai = (4 / NSW) * w8 + k;
                 const int tj = tk.flip ? 20 - 4 * u - bi + ai : 4 * u + bi - ai;
                 const int il = tk.flip ? 4 * tk.rg - DR + 4 * u + bi : 4 * tk.rg + ai;
-                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL;
-                const int g0 = ok ? ((tj * D) * p.H + 2 * il + tk.py) * p.W * 4 : 0;   // byte offset of row ti = 0
-                const int l0 = ai * GL::AI + bi * GL::BI;
-                const unsigned vo = ok ? vin + (unsigned)(r4 * (int)(HW * 4)) : 0x80000000u;
+                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL && 4 * pc < p.W;
+                const unsigned vo = ok ? (unsigned)(((tj * D * p.H + 2 * il + tk.py) * p.W + 4 * pc) * 4) : 0x80000000u;
+                const int l0 = tk.flip ? ai * GL<1>::AI : ai * GL<0>::AI, lt = tk.flip ? GL<1>::TI : GL<0>::TI;
 #pragma unroll
-                for (int tg = 0; tg < 6; ++tg) {
-                    const unsigned v = (tg == 5 && r4 > 0) ? 0x80000000u : vo;     // rows 21 .. 23 do not exist
-                    if (tg < 5 || r4 == 0)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (FN2_LDS(void) *)(smem + l0 + tg * 4 * GL::TI), 16, (int)v, g0 + tg * 4 * (int)(HW * 4), 0, 0);
-                }
+                for (int ti = 0; ti < D; ++ti)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (FN2_LDS(void) *)(smem + l0 + ti * lt), 16, (int)vo, ti * (int)(HW * 4), 0, 0);
             }
         };
-        // X chunk (u, ch): neighbour rows 4rg - 10 + 4u .. +3, channels cg*64 + 32*ch .. +31
-        auto x_issue = [&](XSet &L, const Task &tk, int u, int ch) {
+        // X chunk (u, ch): neighbour rows 4rg - 10 + 4u .. +3, channels cg*64 + 32*ch .. +31; item k of a lane: channel 2 NSW k + s_ch
+        auto x_issue1 = [&](XSet &L, const Task &tk, int u, int ch, int k) {
             const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
             const int il = 4 * tk.rg - DR + 4 * u + s_row;
             const bool ok = il >= 0 && il < HL && s_x < p.W;
             const unsigned vo = ok ? (unsigned)((s_ch * HW + (long)(2 * il + tk.py) * p.W + s_x) * 4) : 0x80000000u;
-#pragma unroll
-            for (int k = 0; k < XK; ++k) {
-                const int soff = (int)((tk.cg * CG + ch * CK + 2 * NSW * k) * HW * 4);
-                if (VAR & 2) { L.v[k][0] = (u4)(0x3c000000u + lane); L.v[k][1] = L.v[k][0]; continue; }
-                L.v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, soff, 0);
-                L.v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(vo + 16), soff, 0);
-            }
+            const int soff = (int)((tk.cg * CG + ch * CK + 2 * NSW * k) * HW * 4);
+            if (VAR & 2) { L.v[k][0] = (u4)(0x3c000000u + lane); L.v[k][1] = L.v[k][0]; return; }
+            L.v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, soff, 0);
+            L.v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(vo + 16), soff, 0);
         };
-        auto x_write = [&](const XSet &L, char *buf) {
+        auto x_issue = [&](XSet &L, const Task &tk, int u, int ch) {
 #pragma unroll
-            for (int k = 0; k < XK; ++k) {
-                if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); continue; }
-                const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]);
-                char *dst = buf + w_ofs + k * 2 * NSW * CHS;
+            for (int k = 0; k < XK; ++k) x_issue1(L, tk, u, ch, k);
+        };
+        auto x_write1 = [&](const XSet &L, char *buf, int k) {
+            if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); return; }
+            const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]);
+            char *dst = buf + w_ofs + k * 2 * NSW * CHS;
 #pragma unroll
-                for (int par = 0; par < 2; ++par) {
-                    const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
-                    const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
-                    const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
-                    const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
-                    *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
-                    *(FN2_LDS(u2) *)(dst + XTERM + par * PARS) = (u2){l01, l23};
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int par = 0; par < 2; ++par) {
+                const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
+                const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
+                const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
+                const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+                *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
+                *(FN2_LDS(u2) *)(dst + XTERM + par * PARS) = (u2){l01, l23};
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
         // the DMA's LDS writes are complete when its vector-memory counter has drained
         auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-        // Invariant at the top of a task: its G(0) is in LDS (or landing), both X chunks of u = 0 are in flight in X0, X1.
-        XSet X0, X1;
+        // Invariant at the top of a task: its G(0) is in LDS (or landing), both X chunks of u = 0 are in flight in set A.
+        // Two register sets: the chunks of u + 1 are requested at the START of phase 1 of u, a whole phase before the G DMA,
+        // so that the DMA does not queue behind them.
+        XSet XA0, XA1, XB0, XB1;
         int t = (int)xcd_remap(blockIdx.x, gridDim.x);
         if (t < ntasks) {
             const Task tk = get_task(t);
-            x_issue(X0, tk, 0, 0);
-            x_issue(X1, tk, 0, 1);
+            x_issue(XA0, tk, 0, 0);
+            x_issue(XA1, tk, 0, 1);
             g_dma(tk, 0);
             stamp(1);
             dma_wait();
@@ -363,12 +369,15 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const bool has_next = t + (int)gridDim.x < ntasks;
             const Task tn = get_task(has_next ? t + (int)gridDim.x : t);
             const bool first = t < (int)gridDim.x;
-            for (int u = 0; u < NU; ++u) {
-                // phase 1 (the matrix waves gather the G operands of u): both X chunks of u; the loads of the next X chunks
-                x_write(X0, smem + X_OFS);
-                x_write(X1, smem + X_OFS + XBUF);
-                if (u + 1 < NU) { x_issue(X0, tk, u + 1, 0); x_issue(X1, tk, u + 1, 1); }
-                else if (has_next) { x_issue(X0, tn, 0, 0); x_issue(X1, tn, 0, 1); }
+            auto one_u = [&](int u, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
+                // phase 1 (the matrix waves gather the G operands of u): request the next X chunks, write both X chunks of u
+                // (all loads first: interleaving them with the items of x_write measured 4 us slower)
+                if (u + 1 < NU) { x_issue(N0, tk, u + 1, 0); x_issue(N1, tk, u + 1, 1); }
+                else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
+#pragma unroll
+                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k);
+#pragma unroll
+                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, k);
                 if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 if (first && u < 2) stamp(5 + 4 * u);
@@ -379,6 +388,10 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 if (first && u < 2) stamp(6 + 4 * u);
                 __syncthreads();                               // (A') the X buffers are free, the next G image complete
                 if (first && u < 2) stamp(7 + 4 * u);
+            };
+            for (int u = 0; u < NU; u += 2) {
+                one_u(u, XA0, XA1, XB0, XB1);
+                one_u(u + 1, XB0, XB1, XA0, XA1);
             }
             if (first) stamp(12);
             __syncthreads();                                   // epilogue image (over the X buffers) complete
@@ -403,8 +416,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         asm volatile("" : "+v"(ln));
         const int f_i = ln & 15, f_g = ln >> 4;                 // pixel / channel index, k group
         const int f_ai = f_i >> 2, f_aj = f_i & 3;
-        // X operand base: lane = (channel i, k group g): block 2j + (g>>1), rows 2(g&1), 2(g&1)+1 -> 16 contiguous bytes
-        const int xb = xpar * PARS + f_i * CHS + (f_g >> 1) * 32 + (f_g & 1) * 16;
+        // X operand base: lane = (channel i, k group g): block 2j + (g&1), rows 2(g>>1), 2(g>>1)+1 -> the 16-byte unit 4j + g
+        const int xb = xpar * PARS + f_i * CHS + f_g * 16;
 
         f4 acc[2][NCT];
 #pragma unroll
@@ -414,21 +427,26 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         h8 gh[NF], gl[NF];   // the G operands of the wave's 6 (centre block, block pair) products
 
         // Gather of the G operands.  Slot s of k group g = neighbour (block m = 2j + blk, row bi = 2gg + (s>>2), column bj = s&3)
-        // with blk = g>>1, gg = g&1, dm = m - a:
+        // with blk = g&1, gg = g>>1, dm = m - a:
         //   FLIP 0: ti = 4 dm + bj - aj + 10, x = 2 (4a + aj) + par      FLIP 1: ti = 10 - 4 dm - bj + aj, x = 2 (4m + bj) + par
-        // byte offset = ai AI + bi BI + ti TI + 4 x = lane part + slot part + (a, j) part; the lane part is recomputed in
+        // byte offset = ai AI + ti TI + bi BI + 4 x = lane part + slot part + (a, j) part; the lane part is recomputed in
         // every call from an opaque copy of the lane id (hoisted out of the u loop it would be 48 live addresses).  The slot
-        // part is kept non-negative (ds_read immediates): FLIP 1 walks bj downwards from 3.
-        auto gather = [&](auto role_c) {
+        // part is kept non-negative (ds_read immediates): FLIP 1 walks bj downwards from 3.  FLIP 0 reads the pixel pair
+        // (8 bytes) and keeps the element of the wave's x parity.
+        auto gather = [&](auto role_c, auto xp_c) {
             constexpr int R = decltype(role_c)::value;
-            typedef GL L;
+            constexpr int XP = decltype(xp_c)::value;          // the wave's x parity, as a constant: picks the pair element for free
+            typedef GL<FLIP> L;
             constexpr int SB = L::TI - 8;                                         // FLIP 1: one column less = one displacement row more
             int l2 = lane;
             asm volatile("" : "+v"(l2));
-            const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = l2 >> 5, gg = (l2 >> 4) & 1;
-            const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * SB + 32 * blk + 4 * xpar
-                                   : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 8 * aj + 4 * xpar;
-            const int t0 = FLIP ? DR - 4 * blk + aj : DR + 4 * blk - aj;        // ti = t0 -+ 4 (2j - a) -+ bj
+            const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = (l2 >> 4) & 1, gg = l2 >> 5;
+            const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * SB + 32 * blk + 4 * XP
+                                   : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 8 * aj;
+            // band test: with sp = 4 blk + bj - aj, ti = 10 +- (4 dj + sp) lies in [0, 21) iff -10 - 4 dj <= sp <= 10 - 4 dj; sp is in
+            // [-3, 7], so only one side can fail for a given dj.  Out-of-band slots are read anyway (any LDS address is harmless) and
+            // replaced by zero: one compare of the lane value vs = 4 blk - aj with a constant and one select per slot.
+            const int vs = 4 * blk - aj;
             static_for<0, 2>([&](auto abc) {
                 constexpr int ab = decltype(abc)::value;
                 constexpr int a = a_blk(R, ab);
@@ -440,18 +458,22 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                         constexpr int pconst = FLIP ? -4 * dj * L::TI + 64 * j : 4 * dj * L::TI + 32 * a;
                         constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
                         const int fbase = lbase + pconst;
-                        const int tb = FLIP ? t0 - 4 * dj : t0 + 4 * dj;          // ti of bj = 0
                         float w[8];
                         static_for<0, 8>([&](auto sc) {
                             constexpr int s = decltype(sc)::value;
                             constexpr int bjs = s & 3, bis = s >> 2;
                             constexpr int sconst = FLIP ? bis * L::BI + (3 - bjs) * SB : bis * L::BI + bjs * L::TI;
-                            int ofs = fbase + sconst;
+                            const int ofs = fbase + sconst;
+                            float v;
+                            if (VAR & 8) v = 1.0f;
+                            else if constexpr (FLIP) v = *reinterpret_cast<const float *>(smem + ofs);
+                            else v = (*reinterpret_cast<const f2 *>(smem + ofs))[XP];
                             if constexpr (check) {
-                                const int ti = FLIP ? tb - bjs : tb + bjs;
-                                ofs = (ti >= 0 && ti < D) ? ofs : ZERO_OFS;
+                                constexpr int hi = 10 - 4 * dj - bjs, lo = -10 - 4 * dj - bjs;   // lo <= vs <= hi
+                                if constexpr (hi < 4) v = vs <= hi ? v : 0.0f;
+                                if constexpr (lo > -3) v = vs >= lo ? v : 0.0f;
                             }
-                            w[s] = (VAR & 8) ? 1.0f : *reinterpret_cast<const float *>(smem + ofs);
+                            w[s] = v;
                         });
                         // two-term split in registers: slots (2q, 2q+1) -> one packed pair of each fragment
                         u4 vh, vl;
@@ -506,13 +528,17 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 }
             });
         };
-        auto gather_d = [&]() {
+        auto gather_x = [&](auto xp_c) {
             switch (role) {
-            case 0: gather(std::integral_constant<int, 0>{}); break;
-            case 1: gather(std::integral_constant<int, 1>{}); break;
-            case 2: gather(std::integral_constant<int, 2>{}); break;
-            default: gather(std::integral_constant<int, 3>{}); break;
+            case 0: gather(std::integral_constant<int, 0>{}, xp_c); break;
+            case 1: gather(std::integral_constant<int, 1>{}, xp_c); break;
+            case 2: gather(std::integral_constant<int, 2>{}, xp_c); break;
+            default: gather(std::integral_constant<int, 3>{}, xp_c); break;
             }
+        };
+        auto gather_d = [&]() {
+            if (xpar) gather_x(std::integral_constant<int, 1>{});
+            else gather_x(std::integral_constant<int, 0>{});
         };
         auto mma_d = [&]() {
             switch (role) {
