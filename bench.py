@@ -197,6 +197,34 @@ def cpu_baseline(max_seconds=30.0):
     }
 
 
+def flownet2c_pass(dev, rank, world, steps, warmup):
+    """the whole FlowNet2C network (harness/) around the HIP layers, bs 8 per GPU at
+    384x512, synthetic data, fp32: training step (forward, MultiScale-L1 loss, backward with overlapped bucketed RCCL
+    all-reduce, Adam), forward+backward alone, and inference.  Reported next to the hot-path numbers, never as `value`."""
+    import dist_utils
+    from harness.train import Trainer, synthetic_batch, time_steps
+    tr = Trainer(dev)
+    inputs, target = synthetic_batch(IMG["B"], IMG["H"], IMG["W"], dev, seed=10 + rank)
+
+    def fwd_bwd():
+        tr.model.train()
+        tr.reducer.zero_grad()
+        tr.reducer.reset()
+        tr.criterion(tr.model(inputs), target)[0].backward()
+        tr.reducer.finish()
+
+    t_train = dist_utils.max_over_ranks(time_steps(lambda: tr.train_step(inputs, target), steps, warmup, dev), device=dev)
+    t_fb = dist_utils.max_over_ranks(time_steps(fwd_bwd, steps, 1, dev), device=dev)
+    t_inf = dist_utils.max_over_ranks(time_steps(lambda: tr.infer(inputs), steps, warmup, dev), device=dev)
+    pairs = IMG["B"] * world
+    return {"model": "FlowNet2C (39 175 298 parameters, random init), bs 8 per GPU @384x512, fp32, synthetic",
+            "steps": steps, "warmup": warmup,
+            "train_step_ms": round(t_train * 1e3, 3), "train_image_pairs_per_s": round(pairs / t_train, 1),
+            "fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_image_pairs_per_s": round(pairs / t_fb, 1),
+            "inference_ms": round(t_inf * 1e3, 3), "inference_image_pairs_per_s": round(pairs / t_inf, 1),
+            "grad_buckets": len(tr.reducer.buckets), "parallelism": f"dp{world}: replica per GPU, bucketed all-reduce overlapped with backward"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +233,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a hipGraph of the step instead of launching it eagerly")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--model", choices=("on", "off"), default="on",
+                    help="also time the whole FlowNet2C network around the layers (extra key `flownet2c`; never `value`)")
+    ap.add_argument("--model-steps", type=int, default=5)
     args = ap.parse_args()
 
     import dist_utils
@@ -274,6 +305,14 @@ def main():
     # The same step through the shipped autograd wrappers (Correlation / Resample2d / ChannelNorm modules, with the
     # difference op of models.py:135 between warp and norm): what a training script pays, allocations included.
     mod_elapsed = hp.module_steps(args.steps)
+
+    model_line = None
+    if args.model == "on":
+        try:
+            model_line = flownet2c_pass(dev, rank, world, args.model_steps, 2)
+        except Exception as exc:   # the hot-path line must not depend on MIOpen finding its kernels
+            print(f"[bench] FlowNet2C pass failed: {exc!r}", file=sys.stderr, flush=True)
+            model_line = {"error": repr(exc)}
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
@@ -364,6 +403,8 @@ def main():
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
         }
+        if model_line is not None:
+            line["flownet2c"] = model_line
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -190,6 +190,117 @@ __global__ __launch_bounds__(256) void resample_bwd_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------- kernel_size > 1 (window sums)
+// The reference adds the four corners at every offset (fy, fx) of a kernel_size x kernel_size window
+// (resample2d_kernel.cu:54-61, :116-123) and, in the flow gradient, at the offsets 0 .. 2 * ((kernel_size-1)/2)
+// (:171-178, :184-191) -- without any bounds test, i.e. it reads and accumulates outside its tensors near the lower
+// and right borders.  Here the shifted indices are clamped to the image (the checker restates it the same way); wherever
+// the reference stays inside its tensors the results are the reference's.  FlowNet2 only uses kernel_size 1
+// (models.py:48,51), so these are plain one-lane-per-pixel kernels with the reference's operation order.
+__global__ __launch_bounds__(256) void resample_fwd_ks_kernel(const float *__restrict__ img, ImgStrides is,
+                                                              const float *__restrict__ flow, float *__restrict__ out,
+                                                              int C, int Hi, int Wi, int H, int W, long npix, int ks, int bilinear)
+{
+    const long HW = (long)H * W;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(g % W);
+        const long row = g / W;
+        const int y = (int)(row % H);
+        const int b = (int)(row / H);
+        const long p = (long)y * W + x;
+        const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float *ib = img + (long)b * is.b;
+        float *ob = out + (long)b * C * HW + p;
+        if (!bilinear) {   // nearest ignores kernel_size (:64-69)
+            const int xN = clampi(clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), 0, Wi - 1);
+            const int yN = clampi(clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1), 0, Hi - 1);
+            for (int c = 0; c < C; ++c) ob[(long)c * HW] = ib[(long)c * is.c + yN * is.h + xN * is.w];
+            continue;
+        }
+        const float fx0 = floorf(xf), fy0 = floorf(yf);
+        const double a = (double)(xf - fx0), be = (double)(yf - fy0);
+        const int xL = clampi(f2i_sat(fx0), 0, W - 1), xR = clampi(f2i_sat(fx0 + 1.0f), 0, W - 1);
+        const int yT = clampi(f2i_sat(fy0), 0, H - 1), yB = clampi(f2i_sat(fy0 + 1.0f), 0, H - 1);
+        const double w00 = (1. - a) * (1. - be), w01 = a * (1. - be), w10 = (1. - a) * be, w11 = a * be;
+        for (int c = 0; c < C; ++c) {
+            const float *ic = ib + (long)c * is.c;
+            float val = 0.0f;
+            for (int fy = 0; fy < ks; ++fy)
+                for (int fx = 0; fx < ks; ++fx) {
+                    const long yt = clampi(yT + fy, 0, Hi - 1) * is.h, yb = clampi(yB + fy, 0, Hi - 1) * is.h;
+                    const long xl = clampi(xL + fx, 0, Wi - 1) * is.w, xr = clampi(xR + fx, 0, Wi - 1) * is.w;
+                    val = val + (float)(w00 * (double)ic[yt + xl]);
+                    val = val + (float)(w01 * (double)ic[yt + xr]);
+                    val = val + (float)(w10 * (double)ic[yb + xl]);
+                    val = val + (float)(w11 * (double)ic[yb + xr]);
+                }
+            ob[(long)c * HW] = val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_bwd_ks_kernel(const float *__restrict__ img, ImgStrides is,
+                                                              const float *__restrict__ flow, const float *__restrict__ gout,
+                                                              float *__restrict__ gimg, float *__restrict__ gflow,
+                                                              int C, int Hi, int Wi, int H, int W, long npix, int ks)
+{
+    const long HW = (long)H * W, HWi = (long)Hi * Wi;
+    const int span = 2 * ((ks - 1) / 2);   // the flow gradient walks offsets 0 .. 2 * kernel_rad (:171, :184)
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(g % W);
+        const long row = g / W;
+        const int y = (int)(row % H);
+        const int b = (int)(row / H);
+        const long p = (long)y * W + x;
+        const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float fx0 = floorf(xf), fy0 = floorf(yf);
+        const int ixL = f2i_sat(fx0), ixR = f2i_sat(fx0 + 1.0f), iyT = f2i_sat(fy0), iyB = f2i_sat(fy0 + 1.0f);
+        // grad_img (:105-123): truncation weights, corners clamped with the image dims, float math
+        const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
+        const int sxL = clampi(ixL, 0, Wi - 1), sxR = clampi(ixR, 0, Wi - 1);
+        const int syT = clampi(iyT, 0, Hi - 1), syB = clampi(iyB, 0, Hi - 1);
+        const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
+        for (int ch = 0; ch < C; ++ch) {
+            const float go = gout[((long)b * C + ch) * HW + p];
+            float *G = gimg + ((long)b * C + ch) * HWi;
+            for (int fy = 0; fy < ks; ++fy)
+                for (int fx = 0; fx < ks; ++fx) {
+                    const long yt = (long)clampi(syT + fy, 0, Hi - 1) * Wi, yb = (long)clampi(syB + fy, 0, Hi - 1) * Wi;
+                    const int xl = clampi(sxL + fx, 0, Wi - 1), xr = clampi(sxR + fx, 0, Wi - 1);
+                    unsafeAtomicAdd(G + yt + xl, s00 * go);
+                    unsafeAtomicAdd(G + yt + xr, s01 * go);
+                    unsafeAtomicAdd(G + yb + xl, s10 * go);
+                    unsafeAtomicAdd(G + yb + xr, s11 * go);
+                }
+        }
+        // grad_flow (:163-192): corners clamped with the flow dims, loops i (x offset), j (y offset), channel
+        const int gxL = clampi(ixL, 0, W - 1), gxR = clampi(ixR, 0, W - 1), gyT = clampi(iyT, 0, H - 1), gyB = clampi(iyB, 0, H - 1);
+        const float gam_y = 1 - (xf - fx0), gam_x = 1 - (yf - fy0);
+        float out_dx = 0.0f, out_dy = 0.0f;
+        for (int i = 0; i <= span; ++i)
+            for (int j = 0; j <= span; ++j)
+                for (int ch = 0; ch < C; ++ch) {
+                    const float go = gout[((long)b * C + ch) * HW + p];
+                    const float *I = img + (long)b * is.b + (long)ch * is.c;
+                    const long yb = clampi(gyB + j, 0, Hi - 1) * is.h, yt = clampi(gyT + j, 0, Hi - 1) * is.h;
+                    const long xl = clampi(gxL + i, 0, Wi - 1) * is.w, xr = clampi(gxR + i, 0, Wi - 1) * is.w;
+                    const float iTL = I[yt + xl], iTR = I[yt + xr], iBL = I[yb + xl], iBR = I[yb + xr];
+                    out_dy = out_dy + (gam_y * go) * iBL;
+                    out_dy = out_dy - (gam_y * go) * iTL;
+                    out_dy = out_dy + ((1 - gam_y) * go) * iBR;
+                    out_dy = out_dy - ((1 - gam_y) * go) * iTR;
+                    out_dx = out_dx + (gam_x * go) * iTR;
+                    out_dx = out_dx - (gam_x * go) * iTL;
+                    out_dx = out_dx + ((1 - gam_x) * go) * iBR;
+                    out_dx = out_dx - ((1 - gam_x) * go) * iBL;
+                }
+        gflow[(long)b * 2 * HW + p] = out_dx;
+        gflow[(long)b * 2 * HW + HW + p] = out_dy;
+    }
+}
+
 // ---------------------------------------------------------------- tiled kernels (LDS windows)
 // With an arbitrary flow every lane of a wave gathers from / scatters to a different cache line; the per-CU
 // vector-memory path then moves a 64-128 B line per 4 useful bytes, and device-scope fp32 atomics to scattered
@@ -618,7 +729,7 @@ static int resample2d_forward_impl(const float *img, const int64_t *img_strides,
 {
     using namespace fn2;
     if (B < 0 || C < 0 || Hi < 1 || Wi < 1 || H < 0 || W < 0) return FN2_EINVAL;
-    if (kernel_size != 1) return FN2_EUNSUPPORTED;
+    if (kernel_size < 1) return FN2_EINVAL;
     if ((long)B * C * H * W == 0) return FN2_OK;
     if (!img || !flow || !out) return FN2_EINVAL;
     if (!aligned(img, 4) || !aligned(flow, 4) || !aligned(out, 4)) return FN2_EALIGN;
@@ -627,6 +738,11 @@ static int resample2d_forward_impl(const float *img, const int64_t *img_strides,
     else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long npix = (long)B * H * W;
+    if (kernel_size != 1) {
+        hipLaunchKernelGGL(resample_fwd_ks_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, out, C, Hi, Wi, H, W,
+                           npix, kernel_size, (bilinear & 1) ? 1 : 0);
+        return launch_status();
+    }
     // tiled path: image rows contiguous and 16 B aligned, same size as the flow, large enough to tile
     const bool tiled_ok = (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && aligned(img, 16) &&
                           (Hi == H) && (Wi == W) && (W % 4 == 0) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
@@ -679,7 +795,7 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
     // both reference backward kernels ignore the bilinear flag; bit 8 of it selects the
     // untiled scatter kernel (profiling / A-B only)
     if (B < 0 || C < 0 || Hi < 1 || Wi < 1 || H < 0 || W < 0) return FN2_EINVAL;
-    if (kernel_size != 1) return FN2_EUNSUPPORTED;
+    if (kernel_size < 1) return FN2_EINVAL;
     if ((long)B * H * W == 0) return FN2_OK;
     if (!img || !flow || !grad_out || !grad_img || !grad_flow) return FN2_EINVAL;
     if (!aligned(img, 4) || !aligned(flow, 4) || !aligned(grad_out, 4) || !aligned(grad_img, 4) || !aligned(grad_flow, 4))
@@ -689,6 +805,11 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
     else { is.b = (long)C * Hi * Wi; is.c = (long)Hi * Wi; is.h = Wi; is.w = 1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long npix = (long)B * H * W;
+    if (kernel_size != 1) {
+        hipLaunchKernelGGL(resample_bwd_ks_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out, grad_img,
+                           grad_flow, C, Hi, Wi, H, W, npix, kernel_size);
+        return launch_status();
+    }
     const bool tiled_ok = (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && aligned(img, 16) &&
                           (Hi == H) && (Wi == W) && (W % 4 == 0) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
     if (tiled_ok) {

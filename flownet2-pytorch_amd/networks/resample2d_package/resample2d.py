@@ -24,9 +24,8 @@ class Resample2dFunction(Function):
         ctx.kernel_size, ctx.bilinear = kernel_size, bilinear
         channels = input1.size(1)
         batch, _, height, width = input2.size()
-        if int(kernel_size) != 1:
-            raise ValueError("Resample2d: kernel_size must be 1 (larger windows read out of bounds in the reference kernel, "
-                             "resample2d_kernel.cu:41-60, and are not implemented here)")
+        if int(kernel_size) < 1:
+            raise ValueError("Resample2d: kernel_size must be >= 1")
         output = input1.new_empty((batch, channels, height, width))   # fully written by the kernel
         resample2d_cuda.forward(input1, input2, output, kernel_size, bilinear)
         return output
@@ -45,8 +44,10 @@ class Resample2dFunction(Function):
 class Resample2d(nn.Module):
     def __init__(self, kernel_size=1, bilinear=True):
         super().__init__()
-        if int(kernel_size) != 1:
-            raise ValueError("Resample2d: kernel_size must be 1 (see Resample2dFunction)")
+        # kernel_size > 1: window sums as in resample2d_kernel.cu:54-61 with the shifted indices clamped to the image (the
+        # reference reads past its tensors there); FlowNet2 itself only uses 1 (models.py:48,51)
+        if int(kernel_size) < 1:
+            raise ValueError("Resample2d: kernel_size must be >= 1")
         self.kernel_size = kernel_size
         self.bilinear = bilinear
 

@@ -124,7 +124,10 @@ int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *gr
  *          just never passes a strided tensor (resample2d.py:9,48)
  *   flow : B x 2 x H x W contiguous (channel 0 = dx, 1 = dy)
  *   out  : B x C x H x W contiguous, fully written
- * kernel_size must be 1 (the reference reads out of bounds for larger values). */
+ * kernel_size >= 1.  For kernel_size > 1 the reference sums the four corners over a kernel_size x kernel_size window of
+ * offsets (:54-61) without a bounds test, i.e. it reads past its tensors near the lower/right border; here the shifted
+ * indices are clamped to the image: identical wherever the reference is defined.
+ * FN2_EINVAL for kernel_size < 1. */
 int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
                            int B, int C, int Hi, int Wi, int H, int W,
                            int kernel_size, int bilinear, void *stream);

@@ -32,6 +32,13 @@ def ref_oracle():
     return Oracle(ref=True)
 
 
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU (run through gpurun)"
+    return torch.device("cuda:0")
+
+
 def golden_files(prefix):
     return sorted(glob.glob(os.path.join(GOLDEN, prefix + "_*.npz")))
 

@@ -51,7 +51,7 @@ def test_rejected_calls_return_codes_without_gpu():
     assert lib.fn2_channelnorm_forward(p, p, 0, 1, 0, 2, 2, null) == -1            # C < 1
     assert lib.fn2_channelnorm_forward(null, p, 0, 1, 1, 2, 2, null) == -1         # null pointer
     assert lib.fn2_channelnorm_forward(p, p, 0, 0, 3, 2, 2, null) == 0             # empty batch: nothing to do
-    assert lib.fn2_resample2d_forward(p, null, p, p, 1, 1, 2, 2, 2, 2, 3, 1, null) == -4   # kernel_size != 1
+    assert lib.fn2_resample2d_forward(p, null, p, p, 1, 1, 2, 2, 2, 2, 0, 1, null) == -1   # kernel_size < 1: FN2_EINVAL
     assert lib.fn2_correlation_forward(p, p, p, 0, 1, 4, 4, 4, 0, 1, 20, 1, 2, null) == -1  # empty output
     assert lib.fn2_correlation_backward(p, p, p, p, p, 0, 1, 4, 8, 8, 4, 1, 4, 2, 2, null) == -4  # stride1 != 1
     assert lib.fn2_correlation_forward_ex(p, p, p, 0, 1, 4, 8, 8, 4, 3, 4, 1, 2, 2, null) == -4   # MFMA path needs k=1

@@ -908,5 +908,29 @@ def test_resample2d_flag_and_kernel_size_handling(dev):
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
-    with pytest.raises(ValueError, match="kernel_size must be 1"):
-        Resample2d(kernel_size=2)
+    with pytest.raises(ValueError, match="kernel_size must be >= 1"):
+        Resample2d(kernel_size=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks", [2, 3, 4])
+@pytest.mark.parametrize("shape", [(2, 3, 32, 64), (1, 2, 9, 13)])
+def test_resample2d_kernel_size_window(dev, oracle, ks, shape):
+    """kernel_size > 1 (window sums, resample2d_kernel.cu:54-61 / :116-123 / :171-191) through the module,
+    forward and both gradients, against the oracle -- including samples whose shifted corners are clamped at the border."""
+    from networks.resample2d_package.resample2d import Resample2d
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(70 + ks)
+    img = (torch.rand(B, C, H, W, generator=g) - 0.5)
+    flow = torch.randn(B, 2, H, W, generator=g) * 3
+    gout = torch.randn(B, C, H, W, generator=g)
+    for bilinear in (True, False):
+        imd, fld = img.to(dev).requires_grad_(True), flow.to(dev).requires_grad_(True)
+        out = Resample2d(kernel_size=ks, bilinear=bilinear)(imd, fld)
+        ref = oracle.resample_fwd(img.numpy(), flow.numpy(), ks, bilinear)
+        assert max_abs(out.detach().cpu().numpy(), ref) <= 1e-5
+        out.backward(gout.to(dev))
+        r1, r2 = oracle.resample_bwd(img.numpy(), flow.numpy(), gout.numpy(), ks, bilinear)
+        # a window sums ks^2 x 4 terms per pixel (grad_img: in atomic order): tolerance relative to the result's magnitude
+        for got, want in ((imd.grad, r1), (fld.grad, r2)):
+            assert max_abs(got.cpu().numpy(), want) <= 1e-5 * (1.0 + float(np.abs(want).max()))

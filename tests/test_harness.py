@@ -1,0 +1,167 @@
+"""the FlowNet2C harness -- network definition (state-dict compatible with the reference's class),
+bucketed gradient all-reduce (world_size-2 gloo on CPU), one training step and inference on the GPU."""
+import importlib
+import os
+import socket
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from conftest import PKG, ROOT
+
+REF = "/root/reference"
+
+
+def test_flownet2c_parameter_table():
+    from harness.flownet2c import FlowNet2C
+    net = FlowNet2C()
+    assert sum(p.numel() for p in net.parameters()) == 39_175_298          # FlowNetC.py:11
+    sd = net.state_dict()
+    assert sd["conv1.0.weight"].shape == (64, 3, 7, 7) and sd["conv3_1.0.weight"].shape == (256, 473, 3, 3)
+    assert sd["deconv2.0.weight"].shape == (386, 64, 4, 4) and sd["upsampled_flow3_to_2.bias"].shape == (2,)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "networks")), reason="reference checkout not present")
+def test_flownet2c_state_dict_matches_reference_class():
+    """Key names and shapes equal those of the reference's models.FlowNet2C, so its checkpoints load unchanged."""
+    from harness.flownet2c import FlowNet2C
+    ours = {k: tuple(v.shape) for k, v in FlowNet2C().state_dict().items()}
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    for k in [k for k in sys.modules if k == "networks" or k.startswith("networks.") or k == "models"]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        ref_models = importlib.import_module("models")
+        ref = ref_models.FlowNet2C(SimpleNamespace(rgb_max=255.0, fp16=False))
+        theirs = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        assert ours == theirs
+        net = FlowNet2C()
+        net.load_state_dict(ref.state_dict())                               # strict
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k not in saved_mods]:
+            del sys.modules[k]
+        sys.modules.update(saved_mods)
+
+
+# ---------------------------------------------------------------- bucketed all-reduce, world_size 2 on gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _small_net():
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(8, 8, 3, padding=1),
+                               torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(8, 2, 3, padding=1))
+
+
+def _ddp_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import dist_utils
+    from harness.ddp import BucketedGradAllReduce
+    dist_utils.init_from_env(backend="gloo")
+    torch.manual_seed(7 + rank)                       # different initial weights: the broadcast must fix that
+    net = _small_net()
+    dist_utils.broadcast_state(net, src=0)
+    plain = _small_net()
+    plain.load_state_dict(net.state_dict())
+    red = BucketedGradAllReduce(net, bucket_bytes=1024)   # several buckets
+    assert len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randn(4, 2, 8, 8, generator=g)
+    lo, hi = dist_utils.shard_bounds(4, world, rank)
+    for step in range(2):
+        red.zero_grad()
+        red.reset()
+        (net(x[lo:hi]) - y[lo:hi]).abs().mean().backward()
+        red.finish()
+        # expected: mean over ranks of the per-rank gradients of the same replica
+        plain.zero_grad()
+        (plain(x[lo:hi]) - y[lo:hi]).abs().mean().backward()
+        for pn, pp in zip(net.parameters(), plain.parameters()):
+            mine = pp.grad.clone()
+            dist.all_reduce(mine)
+            assert torch.allclose(pn.grad, mine / world, rtol=1e-6, atol=1e-7), step
+            assert pn.grad.data_ptr() == red._grad_ptr(pn)          # still a view into its bucket
+    dist.barrier()
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+# ---------------------------------------------------------------- GPU: the network around the HIP layers
+def _corr_torch(a, b):
+    """Independent formulation of FlowNetC's cost volume (kernel 1, displacement 20, stride2 2): 441 shifted products."""
+    H, W = a.shape[2:]
+    bp = F.pad(b, (20, 20, 20, 20))
+    outs = []
+    for tj in range(21):
+        for ti in range(21):
+            dy, dx = 2 * (tj - 10), 2 * (ti - 10)
+            outs.append((a * bp[:, :, 20 + dy:20 + dy + H, 20 + dx:20 + dx + W]).mean(1, keepdim=True))
+    return torch.cat(outs, 1)
+
+
+@pytest.mark.gpu
+def test_flownet2c_forward_paths_agree(dev):
+    from harness.flownet2c import FlowNet2C
+    from harness.train import synthetic_batch
+    torch.manual_seed(1)
+    net = FlowNet2C().to(dev).eval()
+    inputs, _ = synthetic_batch(2, 128, 192, dev, seed=4)
+    with torch.no_grad():
+        fused = net(inputs)                                   # fused LeakyReLU + concat epilogue
+    assert tuple(fused.shape) == (2, 2, 128, 192) and torch.isfinite(fused).all()
+    unfused = net(inputs).detach()                            # grad mode on: Correlation + LeakyReLU + cat
+    scale = float(fused.abs().max())
+    assert float((fused - unfused).abs().max()) <= 1e-5 * scale
+    # the same network with the cost volume formed by plain PyTorch ops
+    class TorchCorr(torch.nn.Module):
+        def forward(self, a, b):
+            return _corr_torch(a, b)
+    hip_corr = net.corr
+    net.corr = TorchCorr()
+    try:
+        ref = net(inputs).detach()
+    finally:
+        net.corr = hip_corr
+    assert float((unfused - ref).abs().max()) <= 2e-4 * scale
+
+
+@pytest.mark.gpu
+def test_flownet2c_train_steps(dev):
+    from harness.train import Trainer, synthetic_batch
+    tr = Trainer(dev, lr=1e-4, seed=2, bucket_bytes=16 << 20)
+    assert len(tr.reducer.buckets) >= 5
+    inputs, target = synthetic_batch(2, 128, 192, dev, seed=5)
+    before = [p.detach().clone() for p in list(tr.model.parameters())[:3]]
+    losses = [float(tr.train_step(inputs, target)[0]) for _ in range(4)]
+    assert all(l == l and l < 1e6 for l in losses)
+    assert losses[-1] < losses[0]                             # same batch four times: Adam must make progress
+    assert any(not torch.equal(b, p) for b, p in zip(before, list(tr.model.parameters())[:3]))
+    flow = tr.infer(inputs)
+    assert tuple(flow.shape) == (2, 2, 128, 192) and torch.isfinite(flow).all()

@@ -41,6 +41,24 @@ def test_resample_live(oracle, ref_oracle):
     assert max_abs(a[0], b[0]) == 0.0 and max_abs(a[1], b[1]) == 0.0
 
 
+@pytest.mark.parametrize("ks", [2, 3])
+def test_resample_kernel_size_live(oracle, ref_oracle, ks):
+    """kernel_size > 1 (resample2d_kernel.cu:54-61, :116-123, :171-191): the reference has no bounds test on the shifted
+    indices, so it is only defined where corner + offset stays inside the image -- a flow that keeps every sample at
+    least kernel_size pixels away from the lower/right border.  There the oracle (which clamps) must agree bit for bit."""
+    rng = np.random.default_rng(50 + ks)
+    B, C, H, W = 2, 3, 12, 14
+    img = rng.uniform(-1, 1, (B, C, H, W)).astype(np.float32)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    tx = rng.uniform(0, W - 2 - ks, (B, H, W)).astype(np.float32)   # target sample position, floor + 1 + (ks-1) <= W - 1
+    ty = rng.uniform(0, H - 2 - ks, (B, H, W)).astype(np.float32)
+    flow = np.stack([tx - xs, ty - ys], axis=1).astype(np.float32)
+    go = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    assert max_abs(oracle.resample_fwd(img, flow, ks, True), ref_oracle.resample_fwd(img, flow, ks, True)) == 0.0
+    a, b = oracle.resample_bwd(img, flow, go, ks), ref_oracle.resample_bwd(img, flow, go, ks)
+    assert max_abs(a[0], b[0]) == 0.0 and max_abs(a[1], b[1]) == 0.0
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_chnorm_live(oracle, ref_oracle, dt):
     rng = np.random.default_rng(6)
