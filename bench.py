@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--model", choices=("on", "off"), default="on",
                     help="also time the whole FlowNet2C network around the layers (extra key `flownet2c`; never `value`)")
     ap.add_argument("--model-steps", type=int, default=5)
+    ap.add_argument("--model-timeout", type=float, default=240.0, help="seconds after which the FlowNet2C pass is abandoned")
     args = ap.parse_args()
 
     import dist_utils
@@ -305,14 +306,6 @@ def main():
     # The same step through the shipped autograd wrappers (Correlation / Resample2d / ChannelNorm modules, with the
     # difference op of models.py:135 between warp and norm): what a training script pays, allocations included.
     mod_elapsed = hp.module_steps(args.steps)
-
-    model_line = None
-    if args.model == "on":
-        try:
-            model_line = flownet2c_pass(dev, rank, world, args.model_steps, 2)
-        except Exception as exc:   # the hot-path line must not depend on MIOpen finding its kernels
-            print(f"[bench] FlowNet2C pass failed: {exc!r}", file=sys.stderr, flush=True)
-            model_line = {"error": repr(exc)}
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
@@ -403,11 +396,35 @@ def main():
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
         }
-        if model_line is not None:
-            line["flownet2c"] = model_line
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+    else:
+        line = None
+
+    # The whole FlowNet2C network around the layers (extra key, never `value`).  All ranks take part (gradient all-reduce);
+    # a watchdog guarantees the one JSON line even if this pass stalls: it prints the hot-path line and ends the process.
+    if args.model == "on":
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["flownet2c"] = {"error": f"no result within {args.model_timeout} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.model_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            model_line = flownet2c_pass(dev, rank, world, args.model_steps, 2)
+        except Exception as exc:   # the hot-path line must not depend on MIOpen finding its kernels
+            print(f"[bench] FlowNet2C pass failed: {exc!r}", file=sys.stderr, flush=True)
+            model_line = {"error": repr(exc)}
+        dog.cancel()
+        if rank == 0:
+            line["flownet2c"] = model_line
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
