@@ -217,12 +217,31 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
     t_fb = dist_utils.max_over_ranks(time_steps(fwd_bwd, steps, 1, dev), device=dev)
     t_inf = dist_utils.max_over_ranks(time_steps(lambda: tr.infer(inputs), steps, warmup, dev), device=dev)
     pairs = IMG["B"] * world
-    return {"model": "FlowNet2C (39 175 298 parameters, random init), bs 8 per GPU @384x512, fp32, synthetic",
+    # BASELINE.json configs[3]: the full FlowNet2 stack (CSS + SD + fusion, 162.5 M parameters), inference, fp32 and with fp16
+    # convolution stacks (the custom layers keep fp32 operands); rank-local, no collective
+    full = {}
+    n_buckets = len(tr.reducer.buckets)
+    try:
+        from harness.flownet2 import FlowNet2
+        tr = None                         # release the FlowNet2C replica, its gradients and optimizer state
+        torch.manual_seed(3)
+        net = FlowNet2().to(dev).eval()
+        with torch.no_grad():
+            t32 = time_steps(lambda: net(inputs), steps, warmup, dev)
+            net16, in16 = net.half(), inputs.half()
+            t16 = time_steps(lambda: net16(in16), steps, warmup, dev)
+        t32 = dist_utils.max_over_ranks(t32, device=dev)
+        t16 = dist_utils.max_over_ranks(t16, device=dev)
+        full = {"flownet2_inference_ms_fp32": round(t32 * 1e3, 3), "flownet2_inference_pairs_per_s_fp32": round(pairs / t32, 1),
+                "flownet2_inference_ms_fp16": round(t16 * 1e3, 3), "flownet2_inference_pairs_per_s_fp16": round(pairs / t16, 1)}
+    except Exception as exc:
+        full = {"flownet2_error": repr(exc)}
+    return {**full, "model": "FlowNet2C (39 175 298 parameters, random init), bs 8 per GPU @384x512, fp32, synthetic",
             "steps": steps, "warmup": warmup,
             "train_step_ms": round(t_train * 1e3, 3), "train_image_pairs_per_s": round(pairs / t_train, 1),
             "fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_image_pairs_per_s": round(pairs / t_fb, 1),
             "inference_ms": round(t_inf * 1e3, 3), "inference_image_pairs_per_s": round(pairs / t_inf, 1),
-            "grad_buckets": len(tr.reducer.buckets), "parallelism": f"dp{world}: replica per GPU, bucketed all-reduce overlapped with backward"}
+            "grad_buckets": n_buckets, "parallelism": f"dp{world}: replica per GPU, bucketed all-reduce overlapped with backward"}
 
 
 def main():

@@ -49,6 +49,30 @@ def test_flownet2c_state_dict_matches_reference_class():
         sys.modules.update(saved_mods)
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "networks")), reason="reference checkout not present")
+def test_flownet2_state_dict_matches_reference_class():
+    """The full stack (FlowNetC + 2 x FlowNetS + FlowNetSD + FlowNetFusion): same keys and shapes as models.FlowNet2."""
+    from harness.flownet2 import FlowNet2
+    ours = FlowNet2()
+    assert sum(p.numel() for p in ours.parameters()) == 162_518_834          # models.py:27
+    mine = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    for k in [k for k in sys.modules if k == "networks" or k.startswith("networks.") or k == "models"]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        ref_models = importlib.import_module("models")
+        ref = ref_models.FlowNet2(SimpleNamespace(rgb_max=255.0, fp16=False))
+        theirs = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        assert mine == theirs
+        ours.load_state_dict(ref.state_dict())
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k not in saved_mods]:
+            del sys.modules[k]
+        sys.modules.update(saved_mods)
+
+
 # ---------------------------------------------------------------- bucketed all-reduce, world_size 2 on gloo
 def _free_port():
     s = socket.socket()
@@ -165,3 +189,28 @@ def test_flownet2c_train_steps(dev):
     assert any(not torch.equal(b, p) for b, p in zip(before, list(tr.model.parameters())[:3]))
     flow = tr.infer(inputs)
     assert tuple(flow.shape) == (2, 2, 128, 192) and torch.isfinite(flow).all()
+
+
+@pytest.mark.gpu
+def test_flownet2_full_stack_inference(dev):
+    """FlowNet2 (CSS + SD + fusion): the fused no-grad path (correlation epilogue, WarpDiffNormCat) against the same network
+    through the separate Correlation / Resample2d / ChannelNorm modules; fp16 convolution stacks stay close to fp32."""
+    from harness.flownet2 import FlowNet2
+    from harness.train import synthetic_batch
+    torch.manual_seed(3)
+    net = FlowNet2().to(dev).eval()
+    # the random-init stack amplifies: scale the weights down so that flows stay within the image
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    inputs, _ = synthetic_batch(2, 128, 192, dev, seed=6)
+    with torch.no_grad():
+        fused = net(inputs)
+    assert tuple(fused.shape) == (2, 2, 128, 192) and torch.isfinite(fused).all()
+    unfused = net(inputs).detach()                    # grad mode: separate modules
+    scale = max(float(unfused.abs().max()), 1e-6)
+    assert float((fused - unfused).abs().max()) <= 1e-3 * scale
+    half = net.half()
+    with torch.no_grad():
+        out16 = half(inputs.half())
+    assert out16.dtype == torch.float16 and torch.isfinite(out16).all()
