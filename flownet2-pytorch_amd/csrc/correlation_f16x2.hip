@@ -79,25 +79,7 @@ __device__ __forceinline__ Task decode_task(const Args &p, bool real, int k)
 template <int VAR>
 __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 64];
-    // VAR 16384 (experiment): the per-step workgroup barrier of the channel loop replaced by two pairs of LDS counters -- the
-    // staging waves count a buffer as filled, the matrix waves as read -- so that a wave only waits for what it depends on
-    // instead of for the slowest of the 16 waves every step.  Monotonic counts over the workgroup's steps; the three
-    // barriers around the epilogue stay (its image aliases the buffers).
-    constexpr bool CNT = (VAR & 16384) != 0;
-    unsigned *cnt_fill = reinterpret_cast<unsigned *>(smem + LDS_BYTES), *cnt_free = cnt_fill + 2;
-    if (CNT && threadIdx.x < 4) cnt_fill[threadIdx.x] = 0u;
-    auto cnt_wait = [&](unsigned *c, unsigned want) __attribute__((always_inline)) {
-        for (int spin = 0; spin < (1 << 20); ++spin) {   // capped: a protocol bug ends in wrong numbers, not in a hung GPU
-            if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-    };
-    auto cnt_signal = [&](unsigned *c) __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    if (CNT) __syncthreads();
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,30 +300,6 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         for (int it = 0; it < n_real; ++it) {
             const Task tk = get_task(it);
             const bool has_next = it + 1 < n_real;
-            if (CNT) {
-                const unsigned g0 = (unsigned)(it * nsteps);            // steps of this workgroup before this task
-                auto put = [&](const LoadSet &L, int s) {               // step s of the task -> buffer s & 1
-                    cnt_wait(cnt_free + (s & 1), 8u * ((g0 + (unsigned)s) >> 1));
-                    stage_write(L, smem + (s & 1) * BUF);
-                    cnt_signal(cnt_fill + (s & 1));
-                };
-                put(L0, 0);
-                for (int s = 0; s + 2 < nsteps; s += 2) {
-                    issue_loads(L0, chunk(it, s + 2));
-                    put(L1, s + 1);
-                    issue_loads(L1, chunk(it, s + 3));
-                    put(L0, s + 2);
-                }
-                set_ctx(get_task(has_next ? it + 1 : it), has_next);
-                issue_loads(L0, chunk(it + 1, 0));
-                put(L1, nsteps - 1);
-                issue_loads(L1, chunk(it + 1, 1));
-                __syncthreads();   // (E1) every matrix wave is through with the buffers
-                __syncthreads();   // (E2) the epilogue image is complete
-                store_rows(tk);
-                __syncthreads();   // (E3) ... and has been read: the buffers are free
-                continue;
-            }
             stage_write(L0, smem);
             if (it < 2) stamp(2 + 6 * it);
             __syncthreads();
@@ -496,17 +454,6 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     for (int it = 0; it < n_real; ++it) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (CNT) {
-            const unsigned g0 = (unsigned)(it * nsteps);
-            for (int s = 0; s < nsteps; ++s) {
-                cnt_wait(cnt_fill + (s & 1), 8u * (((g0 + (unsigned)s) >> 1) + 1u));
-                step_dispatch(smem + (s & 1) * BUF);
-                cnt_signal(cnt_free + (s & 1));
-            }
-            __syncthreads();   // (E1)
-            epilogue(get_task(it), it);   // scatter, (E2), row stores, (E3)
-            continue;
-        }
         __syncthreads();
         if (it < 2) stamp(2 + 6 * it);
         for (int s = 0; s < nsteps; s += 2) {
@@ -578,7 +525,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     const int G = per_stream < 32 ? (int)per_stream : 32;
 #define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3(8u * G), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112) FN2_HF(4096) FN2_HF(16384)
+        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112) FN2_HF(4096)
     default: return FN2_EINVAL;
     }
 #undef FN2_HF

@@ -61,7 +61,7 @@ for algo in (int(v) for v in a.algos.split(",")):
     e.record()
     torch.cuda.synchronize()
     r["b2b_us"] = round(s.elapsed_time(e) * 1e3 / a.batch, 2)
-    if a.check and (algo in (2, 3, 4, 5000, 7000, 21384) or (100 <= algo < 1000 and (algo - 100) % 256 == 0) or (1000 <= algo < 5000 and algo % 10 == 0)):
+    if a.check and (algo in (2, 3, 4, 5000, 7000) or (100 <= algo < 1000 and (algo - 100) % 256 == 0) or (1000 <= algo < 5000 and algo % 10 == 0)):
         if ref is None:
             ref = fn2_capi.correlation_forward(in1, in2, a.md, 1, a.md, 1, 2, algo=1)
         r["max_abs_vs_direct"] = float((out - ref).abs().max())
