@@ -260,8 +260,13 @@ def main():
 
     import dist_utils
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only implementation"
-    rank, world, local_rank = dist_utils.init_from_env()   # backend "nccl" = RCCL; one process per GPU
+    # FN2_BENCH_SHARE_GPU=1: dry run of the N-rank control flow on a box with ONE GPU (all ranks on cuda:0, gloo instead of
+    # RCCL) -- checks the code path, measures nothing; the JSON line says so
+    share = os.environ.get("FN2_BENCH_SHARE_GPU") == "1"
+    rank, world, local_rank = dist_utils.init_from_env(backend="gloo" if share else None)   # "nccl" = RCCL; one process per GPU
     dist = torch.distributed if world > 1 else None
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
@@ -278,7 +283,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if share:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     # The step is seven short launches (0.35 ms of kernels).  The timed region launches them eagerly with ONE event
     # pair per step, around the graded kernel (correlation forward); event pairs around all six ops cost 40 us per
@@ -415,6 +423,8 @@ def main():
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
         }
+        if share:
+            line["dry_run_shared_gpu"] = True
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
