@@ -1,5 +1,5 @@
 // correlation_f16x2_bwd.hip -- correlation backward (both input gradients) on the gfx950 f16 matrix cores, with the
-// operand handling of correlation_f16x2.hip: every fp32 value is split ONCE per staging into two f16 terms
+// operand handling of correlation_f16x2.hip: every fp32 value is split once per use into two f16 terms
 // (x = h + l, h = RNE_f16(x), l = RNE_f16(x - h)) and a product is ah*bh + ah*bl + al*bh in fp32 accumulators.
 //
 // Replaces reference kernels correlation_backward_input1 / correlation_backward_input2
@@ -17,18 +17,19 @@
 // 6 neighbour row blocks u itself (rows 4rg - 10 + 4u .. +3): the sum over neighbours stays in registers, no atomics,
 // deterministic.  Per u:
 //   G image   the 16 (centre row ai, neighbour row bi) combinations x 21 displacement columns x 64 pixels of gO that the
-//             pair (rg, u) touches -- the forward's output tile -- as the raw fp32 rows [ai][bi][ti][x] in LDS, copied by
-//             LDS-DMA (buffer_load_dword ... lds: one 256-byte row per instruction, no VGPRs, no VALU, no ds_write; rows
-//             outside the image / the displacement range arrive as zeros from the buffer range check); strides padded so
-//             that the gather below is conflict-free.  The G operand of (centre block a, neighbour block pair j) is a
-//             GATHER from it: lane (pixel, k group) picks 8 values with ds_read_b32 (one address register + immediates;
-//             values outside the 21-wide band come from a zero word) and splits them into the hi and lo f16 fragments in
-//             registers (an image element is gathered ~1.1 times per u, so splitting here costs what splitting while
-//             staging did -- but the image no longer passes through the staging waves' registers and the LDS store path);
-//             gathered once per u and reused for the 4 channel tiles.
-//   X tile    4 neighbour rows x 64 pixels x 32 channels per chunk, the LDS image of the forward kernel (8-byte chunks of
-//             4 lattice columns, [term][parity][channel][column block][row]): the X operand of (channel tile, block pair)
-//             is two plain ds_read_b128 (hi, lo) -- the neighbour pixels of one channel are contiguous.
+//             pair (rg, u) touches -- the forward's output tile -- as raw fp32 rows [ai][ti][bi][x] in LDS, copied by LDS-DMA
+//             (buffer_load_dwordx4 ... lds: the four rows bi of one (ai, ti) = 1 KB per instruction; no VGPRs, no VALU, no
+//             ds_write; rows outside the image / the displacement range arrive as zeros from the buffer range check); the
+//             ti and ai strides are padded so that the gather below is conflict-free (GL<FLIP>).  The G operand of (centre
+//             block a, neighbour block pair j) is a GATHER from it: lane (pixel, k group) picks 8 values with
+//             ds_read_b32 / b64 (one address register + immediates; slots outside the 21-wide band are read anyway and
+//             replaced by zero) and splits them into the hi and lo f16 fragments in registers (an image element is gathered
+//             ~1.1 times per u, so splitting here costs what splitting while staging would -- but the image does not pass
+//             through the staging waves' registers and the LDS store path); gathered once per u, reused for the 4 channel
+//             tiles.
+//   X tile    4 neighbour rows x 64 pixels x 32 channels per chunk, split once while staging, in the forward kernel's LDS image
+//             (8-byte chunks of 4 lattice columns, [term][parity][channel][...]) with the 16-byte units of a channel ordered
+//             (block pair, row pair, block): the X operand of (channel tile, block pair) is two plain ds_read_b128 (hi, lo).
 // 12 waves per workgroup, 3 per SIMD (168-register budget: 158 used, no scratch), specialised: waves 0-3 stage (the G DMA,
 // buffer loads of X whose range check returns zeros outside the image, X split, LDS writes), waves 4-11 gather and run the
 // MFMAs: matrix wave w takes x parity w&1 and the centre column blocks of role w>>1 ({0,3},{1,2},{4,7},{5,6}: 6 (block, pair)
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         return k;
     };
 
-    // ---- write-out of the epilogue image (all 16 waves): 256 rows (channel, centre row) of 64 floats, 4 rows per instruction
+    // ---- write-out of the epilogue image (all waves): 256 rows (channel, centre row) of 64 floats, 4 rows per instruction
     float *Es = reinterpret_cast<float *>(smem + X_OFS);
     auto store_rows = [&](const Task &tk) {
         int ln = lane;
