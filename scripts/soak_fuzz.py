@@ -20,6 +20,8 @@ while time.time() - t0 < budget:
         C = int(rng.choice([1, 5, 16, 32, 64, 64, 128, 192]))
         H, W, B = int(rng.integers(2, 40)), int(rng.integers(2, 140)), int(rng.integers(1, 4))
         if rng.random() < 0.7: H += H & 1; W += (-W) % 4; C = max(16, C - C % 16)
+        if rng.random() < 0.4:   # shapes the f16x2 matrix-core kernels take (FlowNetC's cost volume on maps up to 64 wide)
+            md, C, H, W = 20, int(rng.choice([64, 128, 192, 256])), 2 * int(rng.integers(1, 31)), 8 * int(rng.integers(1, 9))
         a = rng.standard_normal((B, C, H, W)).astype(np.float32) * np.float32(rng.choice([1e-3, 1.0, 30.0]))
         b = rng.standard_normal((B, C, H, W)).astype(np.float32)
         D2 = (2 * (md // 2) + 1) ** 2
@@ -37,6 +39,7 @@ while time.time() - t0 < budget:
         ncorr += 1
     else:
         B, C, H, W, bil = int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 130)), int(rng.integers(1, 200)), bool(rng.integers(0, 2))
+        ks = int(rng.choice([1, 1, 1, 2, 3]))   # window sums (kernel_size > 1) now and then
         img = rng.standard_normal((B, C, H, W)).astype(np.float32)
         flow = (rng.standard_normal((B, 2, H, W)) * float(rng.choice([0.5, 3.0, 12.0]))).astype(np.float32)
         flow.reshape(-1)[rng.integers(0, flow.size, max(1, flow.size // 40))] *= 40.0
@@ -46,11 +49,12 @@ while time.time() - t0 < budget:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         imd, fld, god = D(img), D(flow), D(gout)
         out = torch.full((B, C, H, W), float("nan"), device=dev)
-        assert lib.fn2_resample2d_forward(P(imd), None, P(fld), P(out), B, C, H, W, H, W, 1, int(bil), st) == 0
-        e = mx(out.cpu().numpy(), orc.resample_fwd(img, flow, 1, bil)); note("resample_fwd", e); assert e <= 1e-4, ("rfwd", B, C, H, W, bil, e)
+        assert lib.fn2_resample2d_forward(P(imd), None, P(fld), P(out), B, C, H, W, H, W, ks, int(bil), st) == 0
+        rf = orc.resample_fwd(img, flow, ks, bil)
+        e = mx(out.cpu().numpy(), rf) / max(1.0, float(np.abs(rf).max())); note("resample_fwd", e); assert e <= 1e-5 * ks * ks + 1e-4 * (ks == 1), ("rfwd", B, C, H, W, bil, ks, e)
         gi, gf = torch.zeros(B, C, H, W, device=dev), torch.full((B, 2, H, W), float("nan"), device=dev)
-        assert lib.fn2_resample2d_backward(P(imd), None, P(fld), P(god), P(gi), P(gf), B, C, H, W, H, W, 1, int(bil), st) == 0
-        rgi, rgf = orc.resample_bwd(img, flow, gout, 1, bil)
+        assert lib.fn2_resample2d_backward(P(imd), None, P(fld), P(god), P(gi), P(gf), B, C, H, W, H, W, ks, int(bil), st) == 0
+        rgi, rgf = orc.resample_bwd(img, flow, gout, ks, bil)
         s = max(1.0, float(np.abs(rgi).max()), float(np.abs(rgf).max()))
         e = max(mx(gi.cpu().numpy(), rgi), mx(gf.cpu().numpy(), rgf)) / s; note("resample_bwd", e); assert e <= 2e-5, ("rbwd", B, C, H, W, bil, e)
         pair = rng.standard_normal((B, 2 * C, H, W)).astype(np.float32)
