@@ -44,13 +44,17 @@ def build_lib(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "flownet2_hip.h"))
-    objs = []
+    objs, jobs = [], []
     for src in KERNEL_SRCS:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         if force or not _newer(o, [s] + hdrs):
-            _run([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
         objs.append(o)
+    if jobs:   # the translation units are independent: compile them side by side (each hipcc is single-threaded)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(_run, jobs))
     if force or not _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
