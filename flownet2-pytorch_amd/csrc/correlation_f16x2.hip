@@ -120,79 +120,69 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         return decode_task(p, false, q0 + pj + pgrp * (i - n_real));
     };
 
-    // ---- write-out of the epilogue image (all 16 waves): rows (plane, ti), 16 planes x 21 = 336 rows; a wave instruction
-    // stores 4 of them, 16 B per lane
+    // ---- write-out of the epilogue image (all 16 waves).  The epilogue is bound by VALU issue like everything else in this
+    // kernel (per SIMD the old version executed ~1.3 k VALU instructions per task: row index divisions, 64-bit addresses,
+    // band selects), so the work is laid out to need almost none: wave w owns plane w = (ai, bi) -- its displacement row tj,
+    // image row and validity are scalars --, a lane owns 16 bytes of the rows ti = (lane >> 4) + 4 i: LDS offsets are one
+    // register + immediates, the global rows are a buffer store with one lane offset and scalar row offsets.
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     float *Os = reinterpret_cast<float *>(smem);
     auto store_rows = [&](const Task &tk) {
         if (VAR & 32) return;
-        // the row geometry depends on the lane only; the opaque copy keeps it from being hoisted out of the task loop
-        // (and spilled) by loop-invariant code motion
+        const int pl = wave, ai = pl >> 2, bi = pl & 3;
+        const int tj = 4 * tk.u + bi - ai, IL = 4 * tk.rg + ai;
+        if (tj < 0 || tj >= D || IL >= HL) return;             // the whole plane lies outside the volume (uniform)
+        const int y = 2 * IL + tk.py;
         int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int xg = 4 * (ln & 15);
-        constexpr int NR = (16 * D + 63) / 64;   // rows per lane group: 6 (the last one partial)
-        auto row_of = [&](int i) { return wave * 4 + (ln >> 4) + 64 * i; };
-        auto read_row = [&](int row) {
-            const int pl = row / D;
-            const int rr = row < 16 * D ? row : 0;
-            return *reinterpret_cast<const f4 *>(Os + rr * O_RS + ((xg + 4 * (4 * (pl & 3) + (pl >> 2))) & 63));
-        };
-        // 1/C, C and the slope are read from the kernel arguments (SGPRs) where they are used.  As VGPR values they live across
-        // the task loop and get spilled, and a scratch reload waits for vmcnt(0), i.e. for the acknowledgement of every row
-        // store issued before it: a wave then has one store in flight instead of six.
+        asm volatile("" : "+v"(ln));   // keeps the lane geometry from being hoisted out of the task loop (and spilled)
+        const int g = ln >> 4, xg = 4 * (ln & 15);
+        constexpr int NR = (D + 3) / 4;   // 6 rows per lane, the last one only for g == 0
+        const float *src = Os + (pl * O_DP + O_SLACK + g) * O_RS + ((xg + 4 * (4 * bi + ai)) & 63);   // + 4 i rows: immediates
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (long)tk.n * p.out_bs, 0, (unsigned)(D * D * HW * 4), 0x00020000);
+        const unsigned vo = xg < p.W ? (unsigned)((g * HW + xg) * 4) : 0x80000000u;   // out-of-range lanes store nothing
+        const int so0 = (int)((((long)tj * D) * p.H + y) * p.W * 4);                    // row ti = 0 of this plane
+        f4 vals[NR];
+        // all LDS reads first, then the arithmetic and the stores: one LDS latency per task instead of one per row
+#pragma unroll
+        for (int i = 0; i < NR; ++i) vals[i] = *reinterpret_cast<const f4 *>(src + 4 * i * O_RS);
+        // 1/C, C and the slope are copied from the kernel arguments (SGPRs) into registers once per call, AFTER the LDS reads were
+        // issued and BEFORE the first store.  (Kept in VGPRs across the task loop they get spilled, and a scratch reload waits for
+        // vmcnt(0), i.e. for the acknowledgement of every row store before it.  Copied by an asm statement between the stores,
+        // the copy can land in a data register of the 16-byte store just issued: the hardware needs a wait state before such a
+        // register is overwritten, the compiler inserts it for its own instructions but not for inline assembly -- the last
+        // lanes of the store then carry 1/C instead of their value.)
+        float r, f = 1.0f, sl = 1.0f;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
+        if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
+        if (p.slope != 1.0f) asm volatile("v_mov_b32 %0, %1" : "=v"(sl) : "s"(p.slope));
         auto finish = [&](f4 val) {
-            float r, f, sl;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
             if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
-            else {
-                asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
-                val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f;
-            }
+            else { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
             if (p.slope != 1.0f) {
-                asm volatile("v_mov_b32 %0, %1" : "=v"(sl) : "s"(p.slope));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * sl;
             }
             return val;
         };
-        auto put = [&](int tj, int ti, int y, f4 val) {
-            f4 *dst = reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg);
-            if (VAR & 1024) *dst = val;
-            else __builtin_nontemporal_store(val, dst);   // written once, not read here: keep the inputs in L2 instead
-        };
-        f4 vals[NR];
-        // all LDS reads first, then the arithmetic and the stores: one LDS latency per task instead of one per row
-#pragma unroll
-        for (int i = 0; i < NR; ++i) vals[i] = read_row(row_of(i));
         unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int row = row_of(i);
-            const int pl = row / D, ti = row - pl * D;
-            const int ai = pl >> 2, bi = pl & 3;
-            const int tj = 4 * tk.u + bi - ai;
-            const int IL = 4 * tk.rg + ai;
-            if (row >= 16 * D || tj < 0 || tj >= D || IL >= HL || xg >= p.W) continue;
-            const u4 bits = __builtin_bit_cast(u4, vals[i]);
-            if ((VAR & 127) == 0 &&
-                (((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
-                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u)))
+            const unsigned v = (4 * i + 3 < D || g == 0) ? vo : 0x80000000u;          // ti = g + 4 i < 21
+            // inf / nan in the image: an operand did not fit an f16 (class mask: sNaN, qNaN, -inf, +inf)
+            if ((VAR & 127) == 0 && (__builtin_amdgcn_classf(vals[i][0], 0x207) | __builtin_amdgcn_classf(vals[i][1], 0x207) |
+                                     __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
-            if (!(VAR & 4)) put(tj, ti, 2 * IL + tk.py, finish(vals[i]));
+            if (!(VAR & 4))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, finish(vals[i])), rso, (int)v, so0 + 4 * i * (int)(HW * 4), (VAR & 1024) ? 0 : 2);
         }
         // An operand did not fit an f16 (or is inf/nan): a second pass recomputes exactly those outputs in fp32 and stores the
         // row again (kept out of the loop above: inlined there, its live state pushes the row values into scratch).
         if (bad) {
 #pragma unroll 1
             for (int i = 0; i < NR; ++i) {
-                if (!(bad >> i & 1)) continue;
-                const int row = row_of(i);
-                const int pl = row / D, ti = row - pl * D;
-                const int ai = pl >> 2, bi = pl & 3;
-                const int tj = 4 * tk.u + bi - ai;
-                const int y = 2 * (4 * tk.rg + ai) + tk.py;
-                f4 val = read_row(row);
+                const int ti = g + 4 * i;
+                if (!(bad >> i & 1) || ti >= D || xg >= p.W) continue;
+                f4 val = *reinterpret_cast<const f4 *>(src + 4 * i * O_RS);
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
                     const float cur = e == 0 ? val[0] : e == 1 ? val[1] : e == 2 ? val[2] : val[3];
@@ -201,7 +191,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                     val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
                     val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
                 }
-                put(tj, ti, y, finish(val));
+                *reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = finish(val);
             }
         }
     };
@@ -395,32 +385,28 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         default: step(std::integral_constant<int, 3>{}, cur); break;
         }
     };
-    // epilogue, first half: accumulators -> LDS [plane = 4 ai + bi][ti][x], 16-byte slots rotated by 4 bi + ai
+    // epilogue, first half: accumulators -> LDS [plane = 4 ai + bi][ti + 3][x], 16-byte slots rotated by 4 bi + ai.  Entries of
+    // the outer block pairs that fall outside the 21-wide band land in the plane's slack rows (never read): every store is
+    // one address register + an immediate, no selects.
     auto scatter = [&](auto role_c) {
         constexpr int R = decltype(role_c)::value;
         int ln = lane;   // opaque copy: see store_rows
         asm volatile("" : "+v"(ln));
         const int e_ai = (ln & 15) >> 2, e_aj = ln & 3, e_bi = ln >> 4;
-        const int prow = (4 * e_ai + e_bi) * D;
         const int rot = 4 * (4 * e_bi + e_ai);
+        const int rbase = ((4 * e_ai + e_bi) * O_DP + O_SLACK + DR - 12 - e_aj) * O_RS;     // row of (dm = -3, r = 0)
         static_for<0, NAB>([&](auto abc) {
             constexpr int ab = decltype(abc)::value;
             constexpr int a = a_blk(R, ab);
-            const int xs = (8 * a + 2 * e_aj + xpar + rot) & 63;
+            float *dst = Os + rbase + ((8 * a + 2 * e_aj + xpar + rot) & 63);
             static_for<0, 7>([&](auto dmc) {
                 constexpr int dm = decltype(dmc)::value - 3;
                 constexpr int pi = pair_idx(R, ab, a + dm);
                 static_for<0, 4>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;   // r = bj
-                    const int ti = 4 * dm + r - e_aj + DR;
+                    constexpr int r = decltype(rc)::value;   // r = bj; ti = 4 dm + r - e_aj + DR
                     float v = 0.0f;                          // B block outside the image: zeros
                     if constexpr (pi >= 0) v = acc[pi][r];
-                    if constexpr (dm >= -1 && dm <= 1) {
-                        Os[(prow + ti) * O_RS + xs] = v;
-                    } else {
-                        const bool ok = (ti >= 0) && (ti < D);
-                        Os[ok ? (prow + ti) * O_RS + xs : O_DUMMY + ln] = v;
-                    }
+                    dst[(4 * (dm + 3) + r) * O_RS] = v;
                 });
             });
         });

@@ -213,60 +213,59 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 
     // ---- write-out of the epilogue image (all waves): 256 rows (channel, centre row) of 64 floats, 4 rows per instruction
     float *Es = reinterpret_cast<float *>(smem + X_OFS);
+    // Laid out for few VALU instructions (the epilogue is issue-bound like the rest): a lane group g = lane >> 4 owns centre
+    // row ai = g, wave w owns channels w, w + NWAVES, ... (scalars): the LDS offset is a lane part + 1 KB per channel, the global
+    // row a buffer store with one lane offset and a scalar channel offset.
     auto store_rows = [&](const Task &tk) {
         int ln = lane;
         asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
-        const int xg = 4 * (ln & 15);
-        constexpr int NRI = (256 + 4 * NWAVES - 1) / (4 * NWAVES);   // row groups per lane
-        auto row_of = [&](int i) { return wave * 4 + (ln >> 4) + 4 * NWAVES * i; };   // row = c * 4 + ai
-        auto read_row = [&](int row) {
-            const int c = row >> 2, ai = row & 3;
-            return *reinterpret_cast<const f4 *>(Es + row * 64 + ((xg + 8 * ai + 32 * ((c >> 2) & 1)) & 63));
-        };
-        auto scaled = [&](f4 val) {
-            // 1/C and C are read from the kernel arguments (SGPRs) where they are used: as VGPR values they live across the
-            // task loop, get spilled, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store
-            // issued before it, which serialises the four stores of a lane (measured: 7 k instead of 2 k ticks per task)
-            float r, f;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
-            if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
-            else {
-                asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
-                val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f;
-            }
-            return val;
-        };
-        auto dst_of = [&](int row) {
-            const int c = row >> 2, ai = row & 3;
-            const int y = 2 * (4 * tk.rg + ai) + tk.py;
-            return reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg);
+        const int g = ln >> 4, xg = 4 * (ln & 15);
+        constexpr int NRI = (CG + NWAVES - 1) / NWAVES;      // channels per wave (the last one partial)
+        const int y = 2 * (4 * tk.rg + g) + tk.py;
+        const bool lane_ok = 4 * tk.rg + g < HL && xg < p.W;
+        const unsigned vo = lane_ok ? (unsigned)((y * p.W + xg) * 4) : 0x80000000u;   // out-of-range lanes store nothing
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.gin[tk.flip] + (long)tk.n * p.C * HW, 0, (unsigned)(p.C * HW * 4), 0x00020000);
+        auto chan = [&](int i) { return wave + NWAVES * i; };
+        auto read_row = [&](int c) {   // Es[c][ai = g][x], 16-byte slots rotated by 8 ai + 32 ((c >> 2) & 1)
+            return *reinterpret_cast<const f4 *>(Es + (c * 4 + g) * 64 + ((xg + 8 * g + 32 * ((c >> 2) & 1)) & 63));
         };
         f4 vals[NRI];
 #pragma unroll
-        for (int i = 0; i < NRI; ++i) vals[i] = read_row(row_of(i) & 255);
+        for (int i = 0; i < NRI; ++i) vals[i] = read_row(chan(i) & (CG - 1));
+        // 1/C and C: copied from the kernel arguments (SGPRs) once per call, before the first store.  (As VGPR values across the
+        // task loop they get spilled, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store
+        // before it.  Copied by an asm statement BETWEEN the stores, the copy can land in a data register of the 16-byte store
+        // just issued: the hardware needs a wait state there that the compiler does not insert for inline assembly.)
+        float r, f = 1.0f;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
+        if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
+        auto scaled = [&](f4 val) {
+            if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
+            else { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
+            return val;
+        };
         unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < NRI; ++i) {
-            const int row = row_of(i);
-            if (row >= 256 || 4 * tk.rg + (row & 3) >= HL || xg >= p.W) continue;
-            const u4 bits = __builtin_bit_cast(u4, vals[i]);
-            if ((VAR & 31) == 0 &&
-                (((bits[0] & 0x7f800000u) == 0x7f800000u) | ((bits[1] & 0x7f800000u) == 0x7f800000u) |
-                 ((bits[2] & 0x7f800000u) == 0x7f800000u) | ((bits[3] & 0x7f800000u) == 0x7f800000u)))
+            const int c = chan(i);
+            if (c >= CG) continue;                                    // uniform
+            // inf / nan: an operand did not fit an f16 (class mask: sNaN, qNaN, -inf, +inf)
+            if ((VAR & 31) == 0 && lane_ok &&
+                (__builtin_amdgcn_classf(vals[i][0], 0x207) | __builtin_amdgcn_classf(vals[i][1], 0x207) |
+                 __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
-            if (!(VAR & 4)) *dst_of(row) = scaled(vals[i]);
+            if (!(VAR & 4))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i])), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 0);
         }
         // Non-finite values (an operand beyond the f16 range): a second pass recomputes exactly those outputs with an fp32 fma
         // chain and stores the row again.  Kept out of the loop above: inlined there, its live state pushes the row values
-        // into scratch, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store before it.
+        // into scratch.
         if (bad) {
 #pragma unroll 1
             for (int i = 0; i < NRI; ++i) {
                 if (!(bad >> i & 1)) continue;
-                const int row = row_of(i);
-                const int c = row >> 2, ai = row & 3;
-                const int y = 2 * (4 * tk.rg + ai) + tk.py;
-                f4 val = read_row(row);
+                const int c = chan(i);
+                f4 val = read_row(c);
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
                     const float cur = e == 0 ? val[0] : e == 1 ? val[1] : e == 2 ? val[2] : val[3];
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                     val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
                     val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
                 }
-                *dst_of(row) = scaled(val);
+                *reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg) = scaled(val);
             }
         }
     };

@@ -27,8 +27,10 @@ constexpr int TILE = 2 * TERM;                    // 36864
 constexpr int BUF = 2 * TILE;                     // 73728: A tile + B tile of one step
 constexpr int LDS_BYTES = 2 * BUF;                // 147456: two steps
 constexpr int O_RS = 64;                          // epilogue row stride (floats)
-constexpr int O_DUMMY = 16 * D * O_RS;            // sink row for out-of-band entries
-static_assert((O_DUMMY + 64) * 4 <= LDS_BYTES, "epilogue image must fit the operand buffers");
+constexpr int O_SLACK = 5;                        // the entries of a block pair reach 5 displacement columns past either end of the
+constexpr int O_DP = D + O_SLACK;                 // band: slack rows take them (no select in the scatter); plane stride 26 rows --
+                                                  // the top slack rows of a plane are the bottom slack rows of the next one
+static_assert((16 * O_DP + O_SLACK) * O_RS * 4 <= LDS_BYTES, "epilogue image must fit the operand buffers");
 
 constexpr int MAX_TAB = 768;                      // tasks per batch item the kernel-argument table holds (H <= 512)
 
