@@ -24,6 +24,7 @@ for d in sorted(glob.glob("gpurun_out/sq_*/")):
     for r in csv.DictReader(open(fs[-1])):
         kn = r["Kernel_Name"]
         if "corr_fwd_f16x2" in kn: k = "corr_fwd_f16x2"
+        elif "corr_bwd_f16x2" in kn: k = "corr_bwd_f16x2"
         elif "corr_fwd_mfma_bf16x3" in kn: k = "corr_fwd_mfma_bf16x3"
         elif "corr_bwd_mfma_bf16x3" in kn: k = "corr_bwd_mfma_bf16x3"
         else: continue
@@ -36,7 +37,9 @@ for k, d in res.items():
     if "SQ_LDS_IDX_ACTIVE" in d and d["SQ_LDS_IDX_ACTIVE"]:
         d["lds_bank_conflict_over_active"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 4)
     if "SQ_INSTS_MFMA" in d and d["SQ_INSTS_MFMA"]:
-        d["valu_per_mfma"] = round(d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"], 3)
+        d["valu_per_mfma"] = round(d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"], 3)   # SQ_INSTS_VALU counts the MFMAs too
+        # MFMA and VALU of a SIMD issue one after the other: per-SIMD issue time if nothing else stalled
+        d["issue_cycles_per_simd_est"] = round((d["SQ_INSTS_MFMA"] * 16 + (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) * 4.25) / 1024.0, 0)
 json.dump(res, open("gpurun_out/sq_counters.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
