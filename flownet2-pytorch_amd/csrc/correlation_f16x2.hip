@@ -39,9 +39,16 @@
 // Epilogue: accumulators -> LDS [plane (ai,bi)][ti][x] (64 floats per row, 16-byte slots rotated by 4 bi + ai: <= 2-way write
 // conflicts, which a ds_write_b32 does not pay for) -> rows leave as 16 B per lane, 4 rows per instruction.
 #include "f16x2_common.h"
+#include "f16x2_split.h"
 
 namespace fn2 {
 namespace hf {
+using f16s::ExpStat;
+using f16s::exp_sample;
+using f16s::post_stat;
+using f16s::scale_exp;
+using f16s::scale_from_exp;
+using f16s::split2;
 
 struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
 
@@ -80,6 +87,10 @@ template <int VAR>
 __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    // exponent statistics {sum, count} of a sample of the first two steps of the NEXT task's A tile [0..1] and B tile [2..3]:
+    // accumulated by the staging waves (ds_add), read by every wave after the following barrier -> the task's two scale
+    // exponents (f16x2_split.h)
+    __shared__ unsigned scl[4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,8 +137,10 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
     // image row and validity are scalars --, a lane owns 16 bytes of the rows ti = (lane >> 4) + 4 i: LDS offsets are one
     // register + immediates, the global rows are a buffer store with one lane offset and scalar row offsets.
     const bool pow2 = (p.C & (p.C - 1)) == 0;
+    const int lgC = pow2 ? 31 - __builtin_clz((unsigned)p.C) : 0;
     float *Os = reinterpret_cast<float *>(smem);
-    auto store_rows = [&](const Task &tk) {
+    // ksum = ka + kb: the matrix-core sums carry 2^ksum (the operand scales of the task); removed with the 1/C, exactly
+    auto store_rows = [&](const Task &tk, int ksum) {
         if (VAR & 32) return;
         const int pl = wave, ai = pl >> 2, bi = pl & 3;
         const int tj = 4 * tk.u + bi - ai, IL = 4 * tk.rg + ai;
@@ -145,19 +158,21 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         // all LDS reads first, then the arithmetic and the stores: one LDS latency per task instead of one per row
 #pragma unroll
         for (int i = 0; i < NR; ++i) vals[i] = *reinterpret_cast<const f4 *>(src + 4 * i * O_RS);
-        // 1/C, C and the slope are copied from the kernel arguments (SGPRs) into registers once per call, AFTER the LDS reads were
-        // issued and BEFORE the first store.  (Kept in VGPRs across the task loop they get spilled, and a scratch reload waits for
+        // Scaling: v_ldexp_f32 by a scalar exponent -- 2^-ksum and, for a power-of-two C, the 1/C in one exact step.  C and the
+        // slope are copied from the kernel arguments (SGPRs) into registers once per call, AFTER the LDS reads were issued and
+        // BEFORE the first store.  (Kept in VGPRs across the task loop they get spilled, and a scratch reload waits for
         // vmcnt(0), i.e. for the acknowledgement of every row store before it.  Copied by an asm statement between the stores,
         // the copy can land in a data register of the 16-byte store just issued: the hardware needs a wait state before such a
         // register is overwritten, the compiler inserts it for its own instructions but not for inline assembly -- the last
-        // lanes of the store then carry 1/C instead of their value.)
-        float r, f = 1.0f, sl = 1.0f;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
+        // lanes of the store then carry the copied value instead of their own.)
+        float f = 1.0f, sl = 1.0f;
         if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
         if (p.slope != 1.0f) asm volatile("v_mov_b32 %0, %1" : "=v"(sl) : "s"(p.slope));
-        auto finish = [&](f4 val) {
-            if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
-            else { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
+        const int kx_mm = -ksum - lgC, kx_ex = -lgC;   // matrix-core sums / sums of the fp32 fallback
+        auto finish = [&](f4 val, int kx) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = __builtin_ldexpf(val[e], kx);
+            if (!pow2) { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
             if (p.slope != 1.0f) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * sl;
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                                      __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
             if (!(VAR & 4))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, finish(vals[i])), rso, (int)v, so0 + 4 * i * (int)(HW * 4), (VAR & 1024) ? 0 : 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, finish(vals[i], kx_mm)), rso, (int)v, so0 + 4 * i * (int)(HW * 4), (VAR & 1024) ? 0 : 2);
         }
         // An operand did not fit an f16 (or is inf/nan): a second pass recomputes exactly those outputs in fp32 and stores the
         // row again (kept out of the loop above: inlined there, its live state pushes the row values into scratch).
@@ -182,16 +197,17 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             for (int i = 0; i < NR; ++i) {
                 const int ti = g + 4 * i;
                 if (!(bad >> i & 1) || ti >= D || xg >= p.W) continue;
+                // the finite entries take the matrix-core scale here, so that the whole row can be finished as fallback values
                 f4 val = *reinterpret_cast<const f4 *>(src + 4 * i * O_RS);
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
                     const float cur = e == 0 ? val[0] : e == 1 ? val[1] : e == 2 ? val[2] : val[3];
-                    if ((__builtin_bit_cast(unsigned, cur) & 0x7f800000u) != 0x7f800000u) continue;
-                    const float ex = exact_corr(p, tk.n, y, xg + e, tj, ti);
+                    const bool nonfin = (__builtin_bit_cast(unsigned, cur) & 0x7f800000u) == 0x7f800000u;
+                    const float ex = nonfin ? exact_corr(p, tk.n, y, xg + e, tj, ti) : __builtin_ldexpf(cur, -ksum);
                     val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
                     val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
                 }
-                *reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = finish(val);
+                *reinterpret_cast<f4 *>(p.out + (long)tk.n * p.out_bs + ((long)(tj * D + ti) * p.H + y) * p.W + xg) = finish(val, kx_ex);
             }
         }
     };
@@ -238,31 +254,45 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                 L.b[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(v_offb + 16), soff, 0);
             }
         };
-        // 8 consecutive pixels -> (hi, lo) x (parity 0, parity 1) chunks of 4 lattice columns
-        auto split_write = [&](const u4 &q0, const u4 &q1, char *dst) {
+        // 8 consecutive pixels -> (hi, lo) x (parity 0, parity 1) chunks of 4 lattice columns, scaled by the tile's sc = 2^k
+        auto split_write = [&](const u4 &q0, const u4 &q1, char *dst, f16s::scale2_t sc) {
             if (VAR & 16) {
                 asm volatile("" ::"v"(q0), "v"(q1));
                 return;
             }
-            const f4 x0 = __builtin_bit_cast(f4, q0), x1 = __builtin_bit_cast(f4, q1);
+            const f4 x0 = f16s::pk_scale4(__builtin_bit_cast(f4, q0), sc), x1 = f16s::pk_scale4(__builtin_bit_cast(f4, q1), sc);
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
-                const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
-                const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
-                const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
-                const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+                unsigned h01, l01, h23, l23;
+                split2(x0[par], x0[2 + par], h01, l01);
+                split2(x1[par], x1[2 + par], h23, l23);
                 *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
                 *(FN2_LDS(u2) *)(dst + TERM + par * PARS) = (u2){l01, l23};
             }
         };
+        f16s::scale2_t sc_a = f16s::scale2_from_exp(0), sc_b = sc_a;   // the current task's operand scales (SGPR pairs)
         auto stage_write = [&](const LoadSet &L, char *buf) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {   // one item at a time: interleaving them costs registers this branch does not have
-                split_write(L.a[k][0], L.a[k][1], buf + w_ofs + k * 16 * CHS);
+                split_write(L.a[k][0], L.a[k][1], buf + w_ofs + k * 16 * CHS, sc_a);
                 __builtin_amdgcn_sched_barrier(0);
-                split_write(L.b[k][0], L.b[k][1], buf + w_ofs + k * 16 * CHS + TILE);
+                split_write(L.b[k][0], L.b[k][1], buf + w_ofs + k * 16 * CHS + TILE, sc_b);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        // sample of a task's first step (32 channels, requested two steps ago: landed) of both tiles: pixels 0 and 2 of each
+        // 16-byte load, 8 values per lane and tile = 4096 per tile -> scl
+        auto post_sample = [&](const LoadSet &L) {
+            ExpStat sa = {0u, 0u}, sb = {0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    exp_sample(sa, L.a[k][h][0]); exp_sample(sa, L.a[k][h][2]);
+                    exp_sample(sb, L.b[k][h][0]); exp_sample(sb, L.b[k][h][2]);
+                }
+            post_stat(scl, sa, lane);
+            post_stat(scl + 2, sb, lane);
         };
 
         // Invariant at the top of a real task: its steps 0 and 1 are in flight in L0 and L1.  During step s buffer s&1 is
@@ -279,10 +309,15 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             issue_loads(L1, chunk(0, 1));
         }
         stamp(1);
+        if (tid < 4) scl[tid] = 0u;
+        __syncthreads();                       // (S0) scale words cleared
+        if (n_real > 0) post_sample(L0);
+        __syncthreads();                       // (S1) ... and hold the first task's sample
+        int ka_n = scale_exp(scl), kb_n = scale_exp(scl + 2);
         auto zero_tasks = [&]() {
             for (int it = n_real; it < n_tasks; ++it) {
                 __syncthreads();
-                store_rows(get_task(it));
+                store_rows(get_task(it), 0);
                 __syncthreads();
             }
         };
@@ -290,9 +325,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         for (int it = 0; it < n_real; ++it) {
             const Task tk = get_task(it);
             const bool has_next = it + 1 < n_real;
+            const int ksum = ka_n + kb_n;
+            sc_a = f16s::scale2_from_exp(ka_n); sc_b = f16s::scale2_from_exp(kb_n);
             stage_write(L0, smem);
             if (it < 2) stamp(2 + 6 * it);
             __syncthreads();
+            if (tid < 4) scl[tid] = 0u;        // every wave has read the words before the barrier above; next use: the epilogue below
             for (int s = 0; s + 2 < nsteps; s += 2) {
                 issue_loads(L0, chunk(it, s + 2));
                 stage_write(L1, smem + BUF);
@@ -310,9 +348,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             issue_loads(L1, chunk(it + 1, 1));
             __syncthreads();
             if (it < 2) stamp(3 + 6 * it);
+            // while the matrix waves scatter their accumulators: the next task's operand sample
+            if (has_next) post_sample(L0);
             __syncthreads();   // the epilogue image is complete
             if (it < 2) stamp(4 + 6 * it);
-            store_rows(tk);
+            ka_n = scale_exp(scl); kb_n = scale_exp(scl + 2);
+            store_rows(tk, ksum);
             if (it < 2) stamp(5 + 6 * it);
             __syncthreads();   // ... and has been read: the buffers are free
             if (it < 2) stamp(6 + 6 * it);
@@ -412,7 +453,8 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         });
     };
 
-    auto epilogue = [&](const Task &tk, int it) {
+    int ka_n = 0, kb_n = 0;
+    auto epilogue = [&](const Task &tk, int it, int ksum) {
         if (it < 2) stamp(3 + 6 * it);
         if (!(VAR & 32)) {
             switch (role) {
@@ -427,17 +469,22 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         }
         __syncthreads();
         if (it < 2) stamp(4 + 6 * it);
-        store_rows(tk);
+        if (it != 99) { ka_n = scale_exp(scl); kb_n = scale_exp(scl + 2); }
+        store_rows(tk, ksum);
         if (it < 2) stamp(5 + 6 * it);
         __syncthreads();
         if (it < 2) stamp(6 + 6 * it);
     };
+    __syncthreads();                           // (S0)
+    __syncthreads();                           // (S1) the first task's operand sample is in scl
+    ka_n = scale_exp(scl); kb_n = scale_exp(scl + 2);
     if (PADS_FIRST) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-        for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99);
+        for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99, 0);
     }
     for (int it = 0; it < n_real; ++it) {
+        const int ksum = ka_n + kb_n;
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
@@ -448,12 +495,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             step_dispatch(smem + BUF);
             __syncthreads();
         }
-        epilogue(get_task(it), it);
+        epilogue(get_task(it), it, ksum);
     }
     if (!PADS_FIRST) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-        for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99);   // zero-only tasks
+        for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99, 0);   // zero-only tasks
     }
     stamp(15);
     dump();

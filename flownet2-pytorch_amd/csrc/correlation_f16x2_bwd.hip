@@ -42,9 +42,16 @@
 #include <type_traits>
 
 #include "corr_params.h"
+#include "f16x2_split.h"
 
 namespace fn2 {
 namespace hb {
+using f16s::ExpStat;
+using f16s::exp_sample;
+using f16s::post_stat;
+using f16s::scale_exp;
+using f16s::scale_from_exp;
+using f16s::split2;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -127,23 +134,6 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-__device__ __forceinline__ float resid_lo(unsigned hp, float x)
-{
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
-    return r;
-}
-__device__ __forceinline__ float resid_hi(unsigned hp, float x)
-{
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
-    return r;
-}
-__device__ __forceinline__ unsigned pk_f16(float a, float b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a, b}, h2));
-}
-
 // one gradient element as a plain fp32 fma chain (cold path: outputs whose matrix-core result is non-finite)
 __device__ __forceinline__ float exact_grad(const Args &p, int flip, int n, int c, int y, int x)
 {
@@ -172,6 +162,9 @@ template <int VAR>
 __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    // exponent statistics {sum, count} of a sample of the NEXT task's first X chunk pair [0..1] and first G image [2..3]: ds_add
+    // by the staging waves, read by every wave after the following barrier -> the task's two scale exponents (f16x2_split.h)
+    __shared__ unsigned scl[4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,6 +175,10 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int per_fn = 2 * p.NRG * p.NCGR;                  // tasks per (flip, batch item)
     const int ntasks = p.nflip * p.B * per_fn;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
+    const int lgC = pow2 ? 31 - __builtin_clz((unsigned)p.C) : 0;
+    // The neighbour row blocks are walked from u = 2 (rows 4rg - 2 .. 4rg + 1: always meets the image) so that the first X
+    // chunks and the first G image of a task -- the samples its operand scales come from -- are never all padding.
+    auto ur = [](int i) { return i + 2 < NU ? i + 2 : i + 2 - NU; };
     if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero words of the gathers (8-byte reads: FLIP 0)
     // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and the first matrix wave during the workgroup's first task
     unsigned long long ts[16];
@@ -216,7 +213,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     // Laid out for few VALU instructions (the epilogue is issue-bound like the rest): a lane group g = lane >> 4 owns centre
     // row ai = g, wave w owns channels w, w + NWAVES, ... (scalars): the LDS offset is a lane part + 1 KB per channel, the global
     // row a buffer store with one lane offset and a scalar channel offset.
-    auto store_rows = [&](const Task &tk) {
+    // ksum = kx + kg: the matrix-core sums carry 2^ksum (the operand scales of the task); removed with the 1/C, exactly
+    auto store_rows = [&](const Task &tk, int ksum) {
         int ln = lane;
         asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
         const int g = ln >> 4, xg = 4 * (ln & 15);
@@ -232,16 +230,18 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         f4 vals[NRI];
 #pragma unroll
         for (int i = 0; i < NRI; ++i) vals[i] = read_row(chan(i) & (CG - 1));
-        // 1/C and C: copied from the kernel arguments (SGPRs) once per call, before the first store.  (As VGPR values across the
-        // task loop they get spilled, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store
+        // Scaling: v_ldexp_f32 by a scalar exponent -- 2^-ksum and, for a power-of-two C, the 1/C in one exact step.  A general C
+        // is copied from the kernel arguments (SGPR) once per call, before the first store.  (As a VGPR value across the
+        // task loop it gets spilled, and a scratch reload waits for vmcnt(0) -- for the acknowledgement of every row store
         // before it.  Copied by an asm statement BETWEEN the stores, the copy can land in a data register of the 16-byte store
         // just issued: the hardware needs a wait state there that the compiler does not insert for inline assembly.)
-        float r, f = 1.0f;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(p.rC));
+        float f = 1.0f;
         if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
-        auto scaled = [&](f4 val) {
-            if (pow2) { val[0] *= r; val[1] *= r; val[2] *= r; val[3] *= r; }
-            else { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
+        const int kx_mm = -ksum - lgC, kx_ex = -lgC;   // matrix-core sums / sums of the fp32 fallback
+        auto scaled = [&](f4 val, int kx) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = __builtin_ldexpf(val[e], kx);
+            if (!pow2) { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
             return val;
         };
         unsigned bad = 0;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                  __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
             if (!(VAR & 4))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i])), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 0);
         }
         // Non-finite values (an operand beyond the f16 range): a second pass recomputes exactly those outputs with an fp32 fma
         // chain and stores the row again.  Kept out of the loop above: inlined there, its live state pushes the row values
@@ -269,12 +269,13 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
                     const float cur = e == 0 ? val[0] : e == 1 ? val[1] : e == 2 ? val[2] : val[3];
-                    if ((__builtin_bit_cast(unsigned, cur) & 0x7f800000u) != 0x7f800000u) continue;
-                    const float ex = exact_grad(p, tk.flip, tk.n, tk.cg * CG + c, y, xg + e);
+                    const bool nonfin = (__builtin_bit_cast(unsigned, cur) & 0x7f800000u) == 0x7f800000u;
+                    // (the finite entries take the matrix-core scale here: the whole row is finished as fallback values)
+                    const float ex = nonfin ? exact_grad(p, tk.flip, tk.n, tk.cg * CG + c, y, xg + e) : __builtin_ldexpf(cur, -ksum);
                     val[0] = e == 0 ? ex : val[0]; val[1] = e == 1 ? ex : val[1];
                     val[2] = e == 2 ? ex : val[2]; val[3] = e == 3 ? ex : val[3];
                 }
-                *reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg) = scaled(val);
+                *reinterpret_cast<f4 *>(p.gin[tk.flip] + (((long)tk.n * p.C + tk.cg * CG + c) * p.H + y) * p.W + xg) = scaled(val, kx_ex);
             }
         }
     };
@@ -330,16 +331,16 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 #pragma unroll
             for (int k = 0; k < XK; ++k) x_issue1(L, tk, u, ch, k);
         };
+        f16s::scale2_t sc_x = f16s::scale2_from_exp(0);   // the current task's X scale (SGPR pair)
         auto x_write1 = [&](const XSet &L, char *buf, int k) {
             if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); return; }
-            const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]);
+            const f4 x0 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][0]), sc_x), x1 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][1]), sc_x);
             char *dst = buf + w_ofs + k * 2 * NSW * CHS;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
-                const float e0 = x0[par], e1 = x0[2 + par], e2 = x1[par], e3 = x1[2 + par];
-                const unsigned h01 = pk_f16(e0, e1), h23 = pk_f16(e2, e3);
-                const unsigned l01 = pk_f16(resid_lo(h01, e0), resid_hi(h01, e1));
-                const unsigned l23 = pk_f16(resid_lo(h23, e2), resid_hi(h23, e3));
+                unsigned h01, l01, h23, l23;
+                split2(x0[par], x0[2 + par], h01, l01);
+                split2(x1[par], x1[2 + par], h23, l23);
                 *(FN2_LDS(u2) *)(dst + par * PARS) = (u2){h01, h23};
                 *(FN2_LDS(u2) *)(dst + XTERM + par * PARS) = (u2){l01, l23};
             }
@@ -347,33 +348,58 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         };
         // the DMA's LDS writes are complete when its vector-memory counter has drained
         auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-        // Invariant at the top of a task: its G(0) is in LDS (or landing), both X chunks of u = 0 are in flight in set A.
-        // Two register sets: the chunks of u + 1 are requested at the START of phase 1 of u, a whole phase before the G DMA,
-        // so that the DMA does not queue behind them.
+        // The operand samples of a task: the first pixel of every 16-byte load of its first X chunk pair (in registers: all 64
+        // channels, 4 neighbour rows; 16 values per lane = 4096) and one dword per lane of every other displacement column of its
+        // first G image (in LDS; this wave's DMA rows: centre row ai = w8, KB-blocks [bi][x]; 11 values per lane = 2816) -> scl.
+        // Runs in the shadow of the matrix waves' last MFMA phase, after the wave's own DMA has landed.
+        auto post_sample = [&](const XSet &S0, const XSet &S1, int flip) {
+            ExpStat sx = {0u, 0u}, sg = {0u, 0u};
+#pragma unroll
+            for (int k = 0; k < XK; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { exp_sample(sx, S0.v[k][h][0]); exp_sample(sx, S1.v[k][h][0]); }
+            if (!(VAR & 2)) {
+                const char *img = smem + (flip ? w8 * GL<1>::AI : w8 * GL<0>::AI) + lane * 16;
+                const int lt = flip ? GL<1>::TI : GL<0>::TI;
+#pragma unroll
+                for (int ti = 0; ti < D; ti += 2) exp_sample(sg, *reinterpret_cast<const unsigned *>(img + ti * lt));
+            }
+            post_stat(scl, sx, lane);
+            post_stat(scl + 2, sg, lane);
+        };
         XSet XA0, XA1, XB0, XB1;
         int t = (int)xcd_remap(blockIdx.x, gridDim.x);
         if (t < ntasks) {
             const Task tk = get_task(t);
-            x_issue(XA0, tk, 0, 0);
-            x_issue(XA1, tk, 0, 1);
-            g_dma(tk, 0);
+            x_issue(XA0, tk, ur(0), 0);
+            x_issue(XA1, tk, ur(0), 1);
+            g_dma(tk, ur(0));
             stamp(1);
+        }
+        if (tid < 4) scl[tid] = 0u;
+        __syncthreads();                                       // (S0) scale words cleared
+        if (t < ntasks) {
             dma_wait();
             stamp(2);
+            post_sample(XA0, XA1, get_task(t).flip);
         }
-        __syncthreads();                                       // (A) G(0) complete
+        __syncthreads();                                       // (A) the first G image complete, the first task's sample in scl
+        int kx_n = scale_exp(scl), kg_n = scale_exp(scl + 2);
         stamp(3);
         for (; t < ntasks; t += gridDim.x) {
             const Task tk = get_task(t);
             const bool has_next = t + (int)gridDim.x < ntasks;
             const Task tn = get_task(has_next ? t + (int)gridDim.x : t);
             const bool first = t < (int)gridDim.x;
-            auto one_u = [&](int u, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
-                // phase 1 (the matrix waves gather the G operands of u): request the next X chunks, write both X chunks of u
+            const int ksum = kx_n + kg_n;
+            sc_x = f16s::scale2_from_exp(kx_n);
+            // i-th neighbour row block of the task: u = ur(i)
+            auto one_u = [&](int i, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
+                const int u = i;   // (stamps)
+                // phase 1 (the matrix waves gather the G operands of block i): request the next X chunks, write both X chunks
                 // (all loads first: interleaving them with the items of x_write measured 4 us slower)
-                if (u + 1 < NU) { x_issue(N0, tk, u + 1, 0); x_issue(N1, tk, u + 1, 1); }
-                else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
+                if (i + 1 < NU) { x_issue(N0, tk, ur(i + 1), 0); x_issue(N1, tk, ur(i + 1), 1); }
+                else if (has_next) { x_issue(N0, tn, ur(0), 0); x_issue(N1, tn, ur(0), 1); }
 #pragma unroll
                 for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k);
 #pragma unroll
@@ -381,10 +407,12 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 if (first && u < 2) stamp(5 + 4 * u);
-                // phase 2 (all MFMAs of u): G(u+1), or G(0) of the next task, by DMA
-                if (u + 1 < NU) g_dma(tk, u + 1);
-                else if (has_next) g_dma(tn, 0);
+                if (i == 0 && tid < 4) scl[tid] = 0u;          // (read by every wave before the task's first barrier)
+                // phase 2 (all MFMAs of block i): the next G image, or the first one of the next task, by DMA
+                if (i + 1 < NU) g_dma(tk, ur(i + 1));
+                else if (has_next) g_dma(tn, ur(0));
                 dma_wait();
+                if (i + 1 == NU && has_next) post_sample(N0, N1, tn.flip);
                 if (first && u < 2) stamp(6 + 4 * u);
                 __syncthreads();                               // (A') the X buffers are free, the next G image complete
                 if (first && u < 2) stamp(7 + 4 * u);
@@ -393,10 +421,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 one_u(u, XA0, XA1, XB0, XB1);
                 one_u(u + 1, XB0, XB1, XA0, XA1);
             }
+            kx_n = scale_exp(scl); kg_n = scale_exp(scl + 2);
             if (first) stamp(12);
             __syncthreads();                                   // epilogue image (over the X buffers) complete
             if (first) stamp(13);
-            store_rows(tk);
+            store_rows(tk, ksum);
             __syncthreads();                                   // image read: the X buffers are free for the next task
             if (first) stamp(14);
         }
@@ -412,8 +441,12 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
 
+    int kx_n = 0, kg_n = 0;   // the next task's scale exponents (read from scl after the barrier that follows their ds_max)
     auto run_task = [&](const Task &tk, auto flipc, bool first) {
         constexpr int FLIP = decltype(flipc)::value;
+        const int ksum = kx_n + kg_n;
+        const float sc_g = scale_from_exp(kg_n);
+        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(kg_n);
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int f_i = ln & 15, f_g = ln >> 4;                 // pixel / channel index, k group
@@ -460,7 +493,9 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                         constexpr int pconst = FLIP ? -4 * dj * L::TI + 64 * j : 4 * dj * L::TI + 32 * a;
                         constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
                         const int fbase = lbase + pconst;
-                        float w[8];
+                        // slots (s, s + 4) -- neighbour rows 2gg and 2gg + 1, one ds_read2st64_b32 -- share a register pair: the scale
+                        // is one v_pk_mul_f32 per pair (FLIP 1; FLIP 0 scales while picking its element of the 8-byte read)
+                        f2 w[4];
                         static_for<0, 8>([&](auto sc) {
                             constexpr int s = decltype(sc)::value;
                             constexpr int bjs = s & 3, bis = s >> 2;
@@ -469,20 +504,25 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                             float v;
                             if (VAR & 8) v = 1.0f;
                             else if constexpr (FLIP) v = *reinterpret_cast<const float *>(smem + ofs);
-                            else v = (*reinterpret_cast<const f2 *>(smem + ofs))[XP];
+                            else v = (*reinterpret_cast<const f2 *>(smem + ofs))[XP] * sc_g;   // pick + scale: one v_mul_f32
                             if constexpr (check) {
                                 constexpr int hi = 10 - 4 * dj - bjs, lo = -10 - 4 * dj - bjs;   // lo <= vs <= hi
                                 if constexpr (hi < 4) v = vs <= hi ? v : 0.0f;
                                 if constexpr (lo > -3) v = vs >= lo ? v : 0.0f;
                             }
-                            w[s] = v;
+                            w[s & 3][s >> 2] = v;
                         });
                         // two-term split in registers: slots (2q, 2q+1) -> one packed pair of each fragment
                         u4 vh, vl;
+                        if constexpr (FLIP) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            vh[q] = pk_f16(w[2 * q], w[2 * q + 1]);
-                            vl[q] = pk_f16(resid_lo(vh[q], w[2 * q]), resid_hi(vh[q], w[2 * q + 1]));
+                            for (int q = 0; q < 4; ++q) w[q] = f16s::pk_scale(w[q], sc_g2);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {   // k slots (2q, 2q + 1) -> one packed pair of each fragment
+                            unsigned hq, lq;
+                            split2(w[(2 * q) & 3][q >> 1], w[(2 * q + 1) & 3][q >> 1], hq, lq);
+                            vh[q] = hq; vl[q] = lq;
                         }
                         gh[fi] = __builtin_bit_cast(h8, vh);
                         gl[fi] = __builtin_bit_cast(h8, vl);
@@ -562,6 +602,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             if (first && u < 2) stamp(7 + 4 * u);
         }
         if (first) stamp(12);
+        kx_n = scale_exp(scl); kg_n = scale_exp(scl + 2);
 
         // epilogue: D[row = channel 4q + r][col = pixel i] -> Es[c][ai][x], 16-byte slots rotated by 8 ai + 32 ((c>>2)&1)
         auto scatter = [&](auto role_c) {
@@ -588,11 +629,13 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         }
         __syncthreads();
         if (first) stamp(13);
-        store_rows(tk);
+        store_rows(tk, ksum);
         __syncthreads();
         if (first) stamp(14);
     };
-    __syncthreads();                                           // (A) G(0) of the first task complete
+    __syncthreads();                                           // (S0)
+    __syncthreads();                                           // (A) the first G image of the first task complete, its sample in scl
+    kx_n = scale_exp(scl); kg_n = scale_exp(scl + 2);
     stamp(3);
     for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
         const Task tk = get_task(t);
