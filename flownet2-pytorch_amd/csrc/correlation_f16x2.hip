@@ -43,12 +43,11 @@
 
 namespace fn2 {
 namespace hf {
-using f16s::ExpStat;
-using f16s::exp_sample;
-using f16s::post_stat;
+using f16s::exp_stat;
 using f16s::scale_exp;
-using f16s::scale_from_exp;
 using f16s::split2;
+using f16s::to_sgpr;
+using f16s::wave_sum;
 
 struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
 
@@ -87,10 +86,9 @@ template <int VAR>
 __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    // exponent statistics {sum, count} of a sample of the first two steps of the NEXT task's A tile [0..1] and B tile [2..3]:
-    // accumulated by the staging waves (ds_add), read by every wave after the following barrier -> the task's two scale
-    // exponents (f16x2_split.h)
-    __shared__ unsigned scl[4];
+    // ka + kb of the current task's operand scales (f16x2_split.h): written by staging wave 0 before the task's first barrier,
+    // read by the matrix waves after it (they undo the scales in the epilogue)
+    __shared__ int scl_ksum;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,19 +278,31 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // sample of a task's first step (32 channels, requested two steps ago: landed) of both tiles: pixels 0 and 2 of each
-        // 16-byte load, 8 values per lane and tile = 4096 per tile -> scl
-        auto post_sample = [&](const LoadSet &L) {
-            ExpStat sa = {0u, 0u}, sb = {0u, 0u};
+        // Operand sample of a task: ONE 16-byte load per lane and tile straight from global memory -- lane l: channel l C / 64, tile
+        // row l & 3, 4 pixels at a pseudo-random column -- 256 values per tile.  EVERY staging wave loads the same 256 + 256 values
+        // and derives the same two exponents: no exchange between the waves, no barrier.  (One load instruction per tile because
+        // a load costs the CU's vector-memory path 16 cycles whatever its width, and that path paces the steps: with four dword
+        // loads per lane and tile the kernel was 1.6 us slower.)  Requested two steps before the task starts, ahead of its first
+        // operand loads, so that they return first; evaluated while the matrix waves scatter the previous task's accumulators.
+        struct Samp { u4 a, b; };
+        auto sample_issue = [&](const Task &tk, Samp &S) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in1 + (long)tk.n * p.C * HW), 0, nbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in2 + (long)tk.n * p.C * HW), 0, nbytes, 0x00020000);
+            const int c = (ln * p.C) >> 6, r = ln & 3, x = 4 * (((((5 * ln) >> 2) & 15) * (p.W >> 2)) >> 4);
+            const int ila = 4 * tk.rg + r, ilb = 4 * tk.rg - DR + 4 * tk.u + r;
+            const unsigned oa = ila < HL ? (unsigned)((c * HW + (long)(2 * ila + tk.py) * p.W + x) * 4) : 0x80000000u;
+            const unsigned ob = (ilb >= 0 && ilb < HL) ? (unsigned)((c * HW + (long)(2 * ilb + tk.py) * p.W + x) * 4) : 0x80000000u;
+            S.a = (VAR & 2) ? (u4)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b128(r1, (int)oa, 0, 0);
+            S.b = (VAR & 2) ? (u4)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b128(r2, (int)ob, 0, 0);
+        };
+        auto sample_scales = [&](const Samp &S, int &ka, int &kb) {
+            unsigned ta = 0u, tb = 0u;
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    exp_sample(sa, L.a[k][h][0]); exp_sample(sa, L.a[k][h][2]);
-                    exp_sample(sb, L.b[k][h][0]); exp_sample(sb, L.b[k][h][2]);
-                }
-            post_stat(scl, sa, lane);
-            post_stat(scl + 2, sb, lane);
+            for (int i = 0; i < 4; ++i) { ta += exp_stat(S.a[i]); tb += exp_stat(S.b[i]); }
+            ka = scale_exp(wave_sum(ta));
+            kb = scale_exp(wave_sum(tb));
         };
 
         // Invariant at the top of a real task: its steps 0 and 1 are in flight in L0 and L1.  During step s buffer s&1 is
@@ -303,17 +313,16 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         // task's place in the list; profiling switch 512 keeps the experiment.)
         auto chunk = [&](int it, int s) { return (VAR & 4096) ? 0 : ((VAR & 512) && (it & 1) ? nsteps - 1 - s : s) * CK; };
         LoadSet L0, L1;
+        Samp SM;
+        int ka_n = 0, kb_n = 0;                // the next task's scale exponents
         if (n_real > 0) {
+            sample_issue(get_task(0), SM);
             set_ctx(get_task(0), true);
             issue_loads(L0, chunk(0, 0));
             issue_loads(L1, chunk(0, 1));
+            sample_scales(SM, ka_n, kb_n);
         }
         stamp(1);
-        if (tid < 4) scl[tid] = 0u;
-        __syncthreads();                       // (S0) scale words cleared
-        if (n_real > 0) post_sample(L0);
-        __syncthreads();                       // (S1) ... and hold the first task's sample
-        int ka_n = scale_exp(scl), kb_n = scale_exp(scl + 2);
         auto zero_tasks = [&]() {
             for (int it = n_real; it < n_tasks; ++it) {
                 __syncthreads();
@@ -327,10 +336,10 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             const bool has_next = it + 1 < n_real;
             const int ksum = ka_n + kb_n;
             sc_a = f16s::scale2_from_exp(ka_n); sc_b = f16s::scale2_from_exp(kb_n);
+            if (tid == 0) scl_ksum = ksum;     // (the matrix waves read the previous task's value right after that task's first barrier)
             stage_write(L0, smem);
             if (it < 2) stamp(2 + 6 * it);
             __syncthreads();
-            if (tid < 4) scl[tid] = 0u;        // every wave has read the words before the barrier above; next use: the epilogue below
             for (int s = 0; s + 2 < nsteps; s += 2) {
                 issue_loads(L0, chunk(it, s + 2));
                 stage_write(L1, smem + BUF);
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             }
             // last two steps: the free register sets receive steps 0 and 1 of the next real task (after the last one the
             // offsets are out of range: the loads return zeros without touching memory)
+            if (has_next) sample_issue(get_task(it + 1), SM);
             set_ctx(get_task(has_next ? it + 1 : it), has_next);
             issue_loads(L0, chunk(it + 1, 0));
             stage_write(L1, smem + BUF);
@@ -348,11 +358,10 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             issue_loads(L1, chunk(it + 1, 1));
             __syncthreads();
             if (it < 2) stamp(3 + 6 * it);
-            // while the matrix waves scatter their accumulators: the next task's operand sample
-            if (has_next) post_sample(L0);
+            // while the matrix waves scatter their accumulators: the next task's scale exponents
+            if (has_next) sample_scales(SM, ka_n, kb_n);
             __syncthreads();   // the epilogue image is complete
             if (it < 2) stamp(4 + 6 * it);
-            ka_n = scale_exp(scl); kb_n = scale_exp(scl + 2);
             store_rows(tk, ksum);
             if (it < 2) stamp(5 + 6 * it);
             __syncthreads();   // ... and has been read: the buffers are free
@@ -453,7 +462,6 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         });
     };
 
-    int ka_n = 0, kb_n = 0;
     auto epilogue = [&](const Task &tk, int it, int ksum) {
         if (it < 2) stamp(3 + 6 * it);
         if (!(VAR & 32)) {
@@ -469,25 +477,21 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         }
         __syncthreads();
         if (it < 2) stamp(4 + 6 * it);
-        if (it != 99) { ka_n = scale_exp(scl); kb_n = scale_exp(scl + 2); }
         store_rows(tk, ksum);
         if (it < 2) stamp(5 + 6 * it);
         __syncthreads();
         if (it < 2) stamp(6 + 6 * it);
     };
-    __syncthreads();                           // (S0)
-    __syncthreads();                           // (S1) the first task's operand sample is in scl
-    ka_n = scale_exp(scl); kb_n = scale_exp(scl + 2);
     if (PADS_FIRST) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         for (int it = n_real; it < n_tasks; ++it) epilogue(get_task(it), 99, 0);
     }
     for (int it = 0; it < n_real; ++it) {
-        const int ksum = ka_n + kb_n;
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
+        const int ksum = to_sgpr(scl_ksum);    // ka + kb of this task's operand scales
         if (it < 2) stamp(2 + 6 * it);
         for (int s = 0; s < nsteps; s += 2) {
             step_dispatch(smem);

@@ -46,12 +46,11 @@
 
 namespace fn2 {
 namespace hb {
-using f16s::ExpStat;
-using f16s::exp_sample;
-using f16s::post_stat;
+using f16s::exp_stat;
 using f16s::scale_exp;
-using f16s::scale_from_exp;
 using f16s::split2;
+using f16s::to_sgpr;
+using f16s::wave_sum;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -162,9 +161,10 @@ template <int VAR>
 __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    // exponent statistics {sum, count} of a sample of the NEXT task's first X chunk pair [0..1] and first G image [2..3]: ds_add
-    // by the staging waves, read by every wave after the following barrier -> the task's two scale exponents (f16x2_split.h)
-    __shared__ unsigned scl[4];
+    // the scale exponents (f16x2_split.h) of the task about to start: [0] = kx + kg (undone in the epilogue), [1] = kg (the matrix
+    // waves scale the G operand).  Written by staging wave 0 before the last barrier of the previous task / barrier (A), read by
+    // the matrix waves after it.
+    __shared__ int scl_k[2];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,9 +176,6 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int ntasks = p.nflip * p.B * per_fn;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const int lgC = pow2 ? 31 - __builtin_clz((unsigned)p.C) : 0;
-    // The neighbour row blocks are walked from u = 2 (rows 4rg - 2 .. 4rg + 1: always meets the image) so that the first X
-    // chunks and the first G image of a task -- the samples its operand scales come from -- are never all padding.
-    auto ur = [](int i) { return i + 2 < NU ? i + 2 : i + 2 - NU; };
     if (tid < 16) reinterpret_cast<unsigned *>(smem + ZERO_OFS)[tid] = 0u;   // the zero words of the gathers (8-byte reads: FLIP 0)
     // VAR 64 (profiling): s_memtime stamps of wave 0 (staging) and the first matrix wave during the workgroup's first task
     unsigned long long ts[16];
@@ -348,43 +345,53 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         };
         // the DMA's LDS writes are complete when its vector-memory counter has drained
         auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-        // The operand samples of a task: the first pixel of every 16-byte load of its first X chunk pair (in registers: all 64
-        // channels, 4 neighbour rows; 16 values per lane = 4096) and one dword per lane of every other displacement column of its
-        // first G image (in LDS; this wave's DMA rows: centre row ai = w8, KB-blocks [bi][x]; 11 values per lane = 2816) -> scl.
-        // Runs in the shadow of the matrix waves' last MFMA phase, after the wave's own DMA has landed.
-        auto post_sample = [&](const XSet &S0, const XSet &S1, int flip) {
-            ExpStat sx = {0u, 0u}, sg = {0u, 0u};
-#pragma unroll
-            for (int k = 0; k < XK; ++k)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) { exp_sample(sx, S0.v[k][h][0]); exp_sample(sx, S1.v[k][h][0]); }
-            if (!(VAR & 2)) {
-                const char *img = smem + (flip ? w8 * GL<1>::AI : w8 * GL<0>::AI) + lane * 16;
-                const int lt = flip ? GL<1>::TI : GL<0>::TI;
-#pragma unroll
-                for (int ti = 0; ti < D; ti += 2) exp_sample(sg, *reinterpret_cast<const unsigned *>(img + ti * lt));
-            }
-            post_stat(scl, sx, lane);
-            post_stat(scl + 2, sg, lane);
+        // Operand sample of a task, straight from global memory, ONE 8-byte load per lane and operand = 128 values each (a load
+        // costs the vector-memory path the same whatever its width; 16 bytes would cost the staging waves a scratch spill): X from
+        // the neighbour rows 4rg - 2 .. 4rg + 1 (u = 2: always meets the image; lane -> channel and row, the column varies), G from
+        // the gO image of the same u (the central displacement rows; lane -> (ai, bi), displacement column and pixel vary).
+        // EVERY staging wave loads the same values and derives the same two exponents: no exchange, no barrier.  Requested at the
+        // start of the previous task's last MFMA phase, evaluated while the matrix waves scatter that task's accumulators.
+        constexpr int U0 = 2;
+        struct Samp { u2 x, g; };
+        auto sample_issue = [&](const Task &tk, Samp &S) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
+            const int ai = ln & 3, bi = (ln >> 2) & 3, q = ln >> 4;
+            const int tj = tk.flip ? 20 - 4 * U0 - bi + ai : 4 * U0 + bi - ai;                 // as g_dma
+            const int ilg = tk.flip ? 4 * tk.rg - DR + 4 * U0 + bi : 4 * tk.rg + ai;
+            const int x = 2 * (((((5 * ln) >> 1) & 31) * (p.W >> 1)) >> 5);
+            const int c = tk.cg * CG + ln, ilx = 4 * tk.rg - DR + 4 * U0 + (ln & 3);
+            const int ti = (5 * q + (ln & 3) + bi) % D;
+            const unsigned ox = (ilx >= 0 && ilx < HL) ? (unsigned)((c * HW + (long)(2 * ilx + tk.py) * p.W + x) * 4) : 0x80000000u;
+            const unsigned og = (ilg >= 0 && ilg < HL) ? (unsigned)((((tj * D + ti) * p.H + 2 * ilg + tk.py) * p.W + x) * 4) : 0x80000000u;
+            S.x = (VAR & 2) ? (u2)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox, 0, 0);
+            S.g = (VAR & 2) ? (u2)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b64(rsg, (int)og, 0, 0);
         };
+        auto sample_scales = [&](const Samp &S, int &kx, int &kg) {
+            const unsigned tx = exp_stat(S.x[0]) + exp_stat(S.x[1]), tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
+            kx = scale_exp(wave_sum(tx));
+            kg = scale_exp(wave_sum(tg));
+        };
+        auto publish = [&](int kx, int kg) { if (tid == 0) { scl_k[0] = kx + kg; scl_k[1] = kg; } };
         XSet XA0, XA1, XB0, XB1;
         int t = (int)xcd_remap(blockIdx.x, gridDim.x);
+        Samp SM;
+        int kx_n = 0, kg_n = 0;                                // the next task's scale exponents
         if (t < ntasks) {
             const Task tk = get_task(t);
-            x_issue(XA0, tk, ur(0), 0);
-            x_issue(XA1, tk, ur(0), 1);
-            g_dma(tk, ur(0));
+            sample_issue(tk, SM);
+            x_issue(XA0, tk, 0, 0);
+            x_issue(XA1, tk, 0, 1);
+            g_dma(tk, 0);
             stamp(1);
-        }
-        if (tid < 4) scl[tid] = 0u;
-        __syncthreads();                                       // (S0) scale words cleared
-        if (t < ntasks) {
             dma_wait();
             stamp(2);
-            post_sample(XA0, XA1, get_task(t).flip);
+            sample_scales(SM, kx_n, kg_n);
+            publish(kx_n, kg_n);
         }
-        __syncthreads();                                       // (A) the first G image complete, the first task's sample in scl
-        int kx_n = scale_exp(scl), kg_n = scale_exp(scl + 2);
+        __syncthreads();                                       // (A) G(0) complete, the first task's exponents published
         stamp(3);
         for (; t < ntasks; t += gridDim.x) {
             const Task tk = get_task(t);
@@ -393,13 +400,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const bool first = t < (int)gridDim.x;
             const int ksum = kx_n + kg_n;
             sc_x = f16s::scale2_from_exp(kx_n);
-            // i-th neighbour row block of the task: u = ur(i)
-            auto one_u = [&](int i, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
-                const int u = i;   // (stamps)
-                // phase 1 (the matrix waves gather the G operands of block i): request the next X chunks, write both X chunks
+            auto one_u = [&](int u, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
+                // phase 1 (the matrix waves gather the G operands of u): request the next X chunks, write both X chunks of u
                 // (all loads first: interleaving them with the items of x_write measured 4 us slower)
-                if (i + 1 < NU) { x_issue(N0, tk, ur(i + 1), 0); x_issue(N1, tk, ur(i + 1), 1); }
-                else if (has_next) { x_issue(N0, tn, ur(0), 0); x_issue(N1, tn, ur(0), 1); }
+                if (u + 1 < NU) { x_issue(N0, tk, u + 1, 0); x_issue(N1, tk, u + 1, 1); }
+                else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
 #pragma unroll
                 for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k);
 #pragma unroll
@@ -407,12 +412,10 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 if (first && u < 2) stamp(5 + 4 * u);
-                if (i == 0 && tid < 4) scl[tid] = 0u;          // (read by every wave before the task's first barrier)
-                // phase 2 (all MFMAs of block i): the next G image, or the first one of the next task, by DMA
-                if (i + 1 < NU) g_dma(tk, ur(i + 1));
-                else if (has_next) g_dma(tn, ur(0));
+                // phase 2 (all MFMAs of u): G(u+1), or G(0) of the next task, by DMA (and the next task's operand sample, ahead of it)
+                if (u + 1 < NU) g_dma(tk, u + 1);
+                else if (has_next) { sample_issue(tn, SM); g_dma(tn, 0); }
                 dma_wait();
-                if (i + 1 == NU && has_next) post_sample(N0, N1, tn.flip);
                 if (first && u < 2) stamp(6 + 4 * u);
                 __syncthreads();                               // (A') the X buffers are free, the next G image complete
                 if (first && u < 2) stamp(7 + 4 * u);
@@ -421,7 +424,9 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 one_u(u, XA0, XA1, XB0, XB1);
                 one_u(u + 1, XB0, XB1, XA0, XA1);
             }
-            kx_n = scale_exp(scl); kg_n = scale_exp(scl + 2);
+            // while the matrix waves scatter their accumulators: the next task's scale exponents (every wave has read the current
+            // ones: the matrix waves do at the top of the task)
+            if (has_next) { sample_scales(SM, kx_n, kg_n); publish(kx_n, kg_n); }
             if (first) stamp(12);
             __syncthreads();                                   // epilogue image (over the X buffers) complete
             if (first) stamp(13);
@@ -441,12 +446,10 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
 
-    int kx_n = 0, kg_n = 0;   // the next task's scale exponents (read from scl after the barrier that follows their ds_max)
     auto run_task = [&](const Task &tk, auto flipc, bool first) {
         constexpr int FLIP = decltype(flipc)::value;
-        const int ksum = kx_n + kg_n;
-        const float sc_g = scale_from_exp(kg_n);
-        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(kg_n);
+        const int ksum = to_sgpr(scl_k[0]);                     // published before the barrier this wave just passed
+        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(to_sgpr(scl_k[1]));
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int f_i = ln & 15, f_g = ln >> 4;                 // pixel / channel index, k group
@@ -466,11 +469,13 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         //   FLIP 0: ti = 4 dm + bj - aj + 10, x = 2 (4a + aj) + par      FLIP 1: ti = 10 - 4 dm - bj + aj, x = 2 (4m + bj) + par
         // byte offset = ai AI + ti TI + bi BI + 4 x = lane part + slot part + (a, j) part; the lane part is recomputed in
         // every call from an opaque copy of the lane id (hoisted out of the u loop it would be 48 live addresses).  The slot
-        // part is kept non-negative (ds_read immediates): FLIP 1 walks bj downwards from 3.  FLIP 0 reads the pixel pair
-        // (8 bytes) and keeps the element of the wave's x parity.
+        // part is kept non-negative (ds_read immediates): FLIP 1 walks bj downwards from 3.  FLIP 0's layout spreads the 32 lanes
+        // of a gather over 32 distinct 8-byte slots (pixel pairs); the wave reads the dword of its x parity in each -- 32 banks
+        // of one parity, conflict-free per half wave like the 8-byte read of round 2, but two slots (s, s + 4) now arrive as one
+        // ds_read2st64_b32 register pair.
         auto gather = [&](auto role_c, auto xp_c) {
             constexpr int R = decltype(role_c)::value;
-            constexpr int XP = decltype(xp_c)::value;          // the wave's x parity, as a constant: picks the pair element for free
+            constexpr int XP = decltype(xp_c)::value;          // the wave's x parity, as a constant: part of the read's immediate offset
             typedef GL<FLIP> L;
             constexpr int SB = L::TI - 8;                                         // FLIP 1: one column less = one displacement row more
             int l2 = lane;
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                         constexpr bool check = dj < -1 || dj + 1 > 1;             // some slot may fall outside the 21-wide band
                         const int fbase = lbase + pconst;
                         // slots (s, s + 4) -- neighbour rows 2gg and 2gg + 1, one ds_read2st64_b32 -- share a register pair: the scale
-                        // is one v_pk_mul_f32 per pair (FLIP 1; FLIP 0 scales while picking its element of the 8-byte read)
+                        // is one v_pk_mul_f32 per pair
                         f2 w[4];
                         static_for<0, 8>([&](auto sc) {
                             constexpr int s = decltype(sc)::value;
@@ -504,7 +509,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                             float v;
                             if (VAR & 8) v = 1.0f;
                             else if constexpr (FLIP) v = *reinterpret_cast<const float *>(smem + ofs);
-                            else v = (*reinterpret_cast<const f2 *>(smem + ofs))[XP] * sc_g;   // pick + scale: one v_mul_f32
+#ifdef FN2_ABL_GATHER64   // round 2: 8-byte gather, element picked in registers
+                            else v = (*reinterpret_cast<const f2 *>(smem + ofs))[XP];
+#else
+                            else v = *reinterpret_cast<const float *>(smem + ofs + 4 * XP);
+#endif
                             if constexpr (check) {
                                 constexpr int hi = 10 - 4 * dj - bjs, lo = -10 - 4 * dj - bjs;   // lo <= vs <= hi
                                 if constexpr (hi < 4) v = vs <= hi ? v : 0.0f;
@@ -514,10 +523,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                         });
                         // two-term split in registers: slots (2q, 2q+1) -> one packed pair of each fragment
                         u4 vh, vl;
-                        if constexpr (FLIP) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) w[q] = f16s::pk_scale(w[q], sc_g2);
-                        }
+                        for (int q = 0; q < 4; ++q) w[q] = f16s::pk_scale(w[q], sc_g2);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {   // k slots (2q, 2q + 1) -> one packed pair of each fragment
                             unsigned hq, lq;
@@ -602,7 +609,6 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             if (first && u < 2) stamp(7 + 4 * u);
         }
         if (first) stamp(12);
-        kx_n = scale_exp(scl); kg_n = scale_exp(scl + 2);
 
         // epilogue: D[row = channel 4q + r][col = pixel i] -> Es[c][ai][x], 16-byte slots rotated by 8 ai + 32 ((c>>2)&1)
         auto scatter = [&](auto role_c) {
@@ -633,9 +639,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         __syncthreads();
         if (first) stamp(14);
     };
-    __syncthreads();                                           // (S0)
-    __syncthreads();                                           // (A) the first G image of the first task complete, its sample in scl
-    kx_n = scale_exp(scl); kg_n = scale_exp(scl + 2);
+    __syncthreads();                                           // (A) G(0) of the first task complete, its scale exponents published
     stamp(3);
     for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
         const Task tk = get_task(t);

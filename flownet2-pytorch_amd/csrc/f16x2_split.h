@@ -10,8 +10,9 @@
 // gradOutput is in training -- kept 2 digits, 1e-8 became 0.  The reference multiplies and adds in fp32 at any magnitude
 // (correlation_cuda_kernel.cu:112,124,214-229).
 //
-// k places the TYPICAL magnitude of the operand -- the mean binary exponent of the non-zero values of a sample of the task's
-// first operand chunk (4096 values: 64 channels of the tile / the first gO image) -- at 2^T_GEO:
+// k places the TYPICAL magnitude of the operand -- the mean binary exponent of the non-zero values of a sample of 256
+// elements spread over the task's operand (all channels of the tile / the gO image of the central displacements), read
+// straight from global memory by one staging wave while the previous task finishes -- at 2^T_GEO:
 //   - values down to 2^-(3 + T_GEO) = 1/32 of the typical magnitude keep >= 22 bits, smaller ones an absolute error of
 //     2^-(25 + T_GEO) = 2^-27 of it: fp32-class sums at any input magnitude;
 //   - values up to 2^(16 - T_GEO) = 16384 x the typical magnitude fit; anything larger makes h infinite, the outputs it
@@ -54,9 +55,13 @@ typedef float f4s __attribute__((ext_vector_type(4)));
 typedef unsigned long long scale2_t;
 __device__ __forceinline__ f2s pk_scale(f2s v, scale2_t s2)
 {
+#ifdef FN2_ABL_NOMUL   // timing ablation (scripts/gpu_ablate.sh): results wrong unless k == 0
+    return v;
+#else
     f2s r;
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(v), "s"(s2));
     return r;
+#endif
 }
 __device__ __forceinline__ f4s pk_scale4(f4s v, scale2_t s2)
 {
@@ -64,17 +69,25 @@ __device__ __forceinline__ f4s pk_scale4(f4s v, scale2_t s2)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-// exponent statistics of a sample: sum of the biased exponents and number of the non-zero (normal) values
-struct ExpStat { unsigned sum, cnt; };
-__device__ __forceinline__ void exp_sample(ExpStat &st, unsigned bits)
+// A value the compiler must keep in an SGPR (v_readfirstlane as assembly: the builtin is dropped when the operand is known to
+// be uniform, and everything derived from it -- e.g. the scale pair of pk_scale -- then lives in vector registers).  The s_nops
+// are the wait states the hazard recognizer inserts around a v_readfirstlane it can see: without the first one the instruction
+// read the register BEFORE the preceding VALU instruction had written it (scripts/ubench/scale_probe.hip).
+__device__ __forceinline__ int to_sgpr(int v)
 {
-    const unsigned e = (bits >> 23) & 0xffu;
-    st.sum += e;
-    st.cnt += e != 0u ? 1u : 0u;
+    int s;
+    asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(s) : "v"(v));
+    return s;
 }
 
-// wave-wide sum (DPP butterflies inside the rows of 16, the four rows on the scalar unit) -> SGPR
-__device__ __forceinline__ unsigned wave_sum(unsigned b)
+// Exponent statistics of a sample of NS values per lane (one wave): biased exponents of the non-zero values, count in the
+// upper half word.  One packed DPP reduction; the result is wave-uniform (SGPR).
+__device__ __forceinline__ unsigned exp_stat(unsigned bits)   // one value -> (e != 0) << 16 | e
+{
+    const unsigned e = (bits >> 23) & 0xffu;
+    return e + ((e != 0u ? 1u : 0u) << 16);
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned b)      // DPP butterflies inside the rows of 16, the four rows on the scalar unit
 {
     b += (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
     b += (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
@@ -84,30 +97,14 @@ __device__ __forceinline__ unsigned wave_sum(unsigned b)
            __builtin_amdgcn_readlane(b, 48);
 }
 
-// a wave's share of a sample -> the workgroup's two LDS words {sum, cnt}
-__device__ __forceinline__ void post_stat(unsigned *words, const ExpStat &st, int lane)
+// exponent k of the scale 2^k from a wave's packed statistics (sum of the lanes' exp_stat values; <= 256 samples: no carry
+// into the count).  No non-zero value in the sample: k = 0, the unscaled split.
+__device__ __forceinline__ int scale_exp(unsigned packed)
 {
-    const unsigned s = wave_sum(st.sum), c = wave_sum(st.cnt);
-    if (lane == 0) {
-        __hip_atomic_fetch_add(&words[0], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&words[1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-// exponent k of the scale 2^k from the sample's {sum, cnt} (wave-uniform; every wave computes the same value).
-// No non-zero value in the sample: k = 0, the unscaled split.
-__device__ __forceinline__ int scale_exp(const unsigned *words)
-{
-    const unsigned sum = __builtin_amdgcn_readfirstlane(words[0]), cnt = __builtin_amdgcn_readfirstlane(words[1]);
+    const unsigned sum = packed & 0xffffu, cnt = packed >> 16;
     if (cnt == 0u) return 0;
     const int e = (int)((float)sum * __builtin_amdgcn_rcpf((float)cnt) + 0.5f);   // mean biased exponent, 1 .. 255
-    // (as assembly: the compiler drops a readfirstlane builtin of a value it knows to be uniform and then keeps the exponent --
-    // and every scale derived from it -- in vector registers.  The s_nops are the wait states the hazard recognizer would
-    // insert around a v_readfirstlane it can see: without the first one the instruction read the register BEFORE the
-    // preceding v_cvt_i32_f32 had written it -- scripts/ubench/scale_probe.hip)
-    int es;
-    asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(es) : "v"(e));
-    const int k = T_GEO + 127 - es;                                                // -126 .. 128
+    const int k = T_GEO + 127 - to_sgpr(e);                                        // -126 .. 128
     return k > 127 ? 127 : k;
 }
 __device__ __forceinline__ float scale_from_exp(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
