@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the FlowNet2 custom-layer hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: starts its own N ranks (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -214,7 +214,7 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
         tr.reducer.finish()
 
     t_train = dist_utils.max_over_ranks(time_steps(lambda: tr.train_step(inputs, target), steps, warmup, dev), device=dev)
-    t_fb = dist_utils.max_over_ranks(time_steps(fwd_bwd, steps, 1, dev), device=dev)
+    t_fb = dist_utils.max_over_ranks(time_steps(fwd_bwd, steps, warmup, dev), device=dev)
     t_inf = dist_utils.max_over_ranks(time_steps(lambda: tr.infer(inputs), steps, warmup, dev), device=dev)
     pairs = IMG["B"] * world
     # BASELINE.json configs[3]: the full FlowNet2 stack (CSS + SD + fusion, 162.5 M parameters), inference, fp32 and with fp16
@@ -244,6 +244,63 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
             "grad_buckets": n_buckets, "parallelism": f"dp{world}: replica per GPU, bucketed all-reduce overlapped with backward"}
 
 
+def launch_plan(gpus, device_count, share):
+    """How `--gpus N` is started when no launcher set WORLD_SIZE: the per-rank environments (one process per GPU, RCCL over
+    127.0.0.1 rendezvous) or an error string.  Pure function: tests/test_bench_launch.py covers it on CPU."""
+    if gpus < 1:
+        return None, "--gpus must be >= 1"
+    if gpus == 1:
+        return [], None                       # run in this process
+    if device_count < gpus and not share:
+        return None, (f"--gpus {gpus} but only {device_count} GPU(s) visible (FN2_BENCH_SHARE_GPU=1 runs the N-rank control "
+                      "flow on one GPU over gloo as a dry run)")
+    return [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "MASTER_ADDR": "127.0.0.1",
+             "LOCAL_WORLD_SIZE": str(gpus)} for r in range(gpus)], None
+
+
+def self_launch(argv, gpus, share):
+    """`python bench.py --gpus N` (N > 1, no torchrun): re-runs this script as N ranks, one per GPU, rank 0 inheriting stdout
+    so that the ONE JSON line is its line (the reference scales with one command too: main.py:187-201).  Returns the exit code."""
+    import socket
+    import subprocess
+    plan, err = launch_plan(gpus, torch.cuda.device_count(), share)
+    if err:
+        print("[bench] " + err, file=sys.stderr, flush=True)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for env_r in plan:
+        env = dict(os.environ, **env_r, MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if env_r["RANK"] == "0" else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("FN2_BENCH_LAUNCH_TIMEOUT", "1500"))
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            r = pr.poll()
+            if r is not None:
+                live.remove(pr)
+                if r != 0 and rc == 0:
+                    rc = r
+        if (rc != 0 or time.time() > deadline) and live:   # one rank failed (or the job hangs): stop exactly the ranks we started
+            for pr in live:
+                pr.terminate()
+            for pr in live:
+                try:
+                    pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,7 +311,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--model", choices=("on", "off"), default="on",
                     help="also time the whole FlowNet2C network around the layers (extra key `flownet2c`; never `value`)")
-    ap.add_argument("--model-steps", type=int, default=5)
+    ap.add_argument("--model-steps", type=int, default=20)
+    ap.add_argument("--model-warmup", type=int, default=5)
     ap.add_argument("--model-timeout", type=float, default=240.0, help="seconds after which the FlowNet2C pass is abandoned")
     args = ap.parse_args()
 
@@ -263,6 +321,8 @@ def main():
     # FN2_BENCH_SHARE_GPU=1: dry run of the N-rank control flow on a box with ONE GPU (all ranks on cuda:0, gloo instead of
     # RCCL) -- checks the code path, measures nothing; the JSON line says so
     share = os.environ.get("FN2_BENCH_SHARE_GPU") == "1"
+    if args.gpus != 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus, share))
     rank, world, local_rank = dist_utils.init_from_env(backend="gloo" if share else None)   # "nccl" = RCCL; one process per GPU
     dist = torch.distributed if world > 1 else None
     if share:
@@ -318,7 +378,18 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     elapsed = dist_utils.max_over_ranks(elapsed, device=dev)   # the step time is the slowest rank's
+    # per-rank consistency check: every rank's own time for its K steps and a checksum of its results
+    chk = float(hp.out.double().sum().item() + hp.g1.double().sum().item() + hp.norm.double().sum().item())
+    mine = torch.tensor([own_elapsed, chk, float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+    if dist is not None:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    per_rank = [{"rank": r, "device": int(t[2].item()), "ms_per_step": round(float(t[0].item()) / args.steps * 1e3, 4),
+                 "finite": bool(torch.isfinite(t[1]).item())} for r, t in enumerate(allr)]
 
     # Per-kernel durations: the same K steps once more with a HIP event pair around every op on the launch stream
     # (same kernels, same inputs; rocprofv3's per-kernel averages of this command agree).
@@ -345,11 +416,17 @@ def main():
                        "frac_of_8TBps": round(ab[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                    for k, ms in per_op_ms.items()}
         cf = kernels["corr_fwd"]
-        traffic = None
+        # HBM-side traffic of the graded kernel: NOT measured in this process (PMC counters need their own rocprofv3 --pmc
+        # passes, scripts/gpu_traffic.sh); the tracked result of those passes is quoted with its source
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "corr_fwd_hbm_traffic.json")
-        if os.path.exists(tpath):   # PMC pass (separate rocprofv3 --pmc run), bytes per launch, corrected per the guide
+        if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("bytes_per_launch")
+                traffic_src = ("quoted from profiles/corr_fwd_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                               "passes, FETCH_SIZE doubled per the guide's gfx950 correction; kernel source at commit "
+                               f"{tj.get('commit', 'unrecorded')}), not measured in this run")
             except Exception:
                 traffic = None
         # what an event pair adds around ONE short kernel (launch latency + inter-packet gaps): a 4-byte fill
@@ -360,18 +437,41 @@ def main():
         torch.cuda.synchronize()
         event_floor_ms = sorted(s_.elapsed_time(e_) for s_, e_ in nev)[len(nev) // 2]
         pairs = CORR["B"] * args.steps * world
-        # empirical streaming ceiling of this box: device-to-device copy of 1 GiB, read + write bytes
+        # empirical streaming ceiling of this box: device-to-device copy of 1 GiB, read + write bytes -- a float4
+        # grid-stride kernel (fn2_debug_stream_copy in the debug library; the guide quotes 6.29 TB/s for such a copy), best of a
+        # few grid sizes and of temporal / non-temporal accesses; torch's copy_ for comparison
         src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
         dst = torch.empty_like(src)
-        dst.copy_(src)
-        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-        for s_, e_ in cev:
-            s_.record(); dst.copy_(src); e_.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2 * src.numel() * 4 / (min(s_.elapsed_time(e_) for s_, e_ in cev) * 1e-3) / 1e9
+
+        def best_gbs(fn, reps=5):
+            fn()
+            cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for s_, e_ in cev:
+                s_.record(); fn(); e_.record()
+            torch.cuda.synchronize()
+            return 2 * src.numel() * 4 / (min(s_.elapsed_time(e_) for s_, e_ in cev) * 1e-3) / 1e9
+
+        copy_torch = best_gbs(lambda: dst.copy_(src))
+        copy_gbs, copy_kernel = copy_torch, "torch Tensor.copy_"
+        try:
+            import ctypes
+            import fn2_capi
+            dl = fn2_capi.debug_lib()
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for blocks in (2048, 4096, 8192, 16384):
+                for nt in (0, 1):
+                    g_ = best_gbs(lambda: fn2_capi.check(dl.fn2_debug_stream_copy(
+                        ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(src.numel() * 4),
+                        blocks, nt, st), "fn2_debug_stream_copy"), reps=3)
+                    if g_ > copy_gbs:
+                        copy_gbs, copy_kernel = g_, f"float4 grid-stride copy, {blocks} x 256 lanes, {'non-' if nt else ''}temporal"
+        except Exception as exc:   # debug library not built: keep torch's number and say so
+            copy_kernel += f" (fn2_debug_stream_copy unavailable: {exc!r})"
         del src, dst
         line = {
-            "metric": "image-pairs/sec",
+            "metric": "image-pairs/sec, FlowNet2 custom-layer hot path (Correlation + Resample2d + ChannelNorm) fwd+bwd @ 384x512 "
+                      "bs8 -- the whole FlowNet2C network's fwd+bwd image-pairs/sec is flownet2c.fwd_bwd_image_pairs_per_s; "
+                      "corr-layer HBM GB/s vs roofline is `roofline`",
             "value": round(pairs / elapsed, 3),
             "unit": "image-pairs/s",
             "n_gpus": world,
@@ -404,7 +504,11 @@ def main():
                 "unit": "GB/s",
                 "frac": round(cf["achieved_GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_src,
+                "frac_of_copy_ceiling": round(cf["achieved_GBps"] / copy_gbs, 4),
                 "copy_ceiling_GBps": round(copy_gbs, 1),
+                "copy_ceiling_kernel": copy_kernel,
+                "copy_ceiling_torch_copy_GBps": round(copy_torch, 1),
                 "launch_ms": cf["ms"],
                 "event_pair_floor_ms": round(event_floor_ms, 5),   # the same event pair around a 4-byte fill: rocprofv3's kernel
                                                                   # durations are shorter than launch_ms by about this much
@@ -422,7 +526,9 @@ def main():
                         "row-block pair); the kernel is bound by instruction issue and LDS, not by the matrix pipe (DESIGN.md 4.1)"})(
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
+            "per_rank": per_rank,
         }
+        assert len(per_rank) == world and all(r["finite"] for r in per_rank), per_rank
         if share:
             line["dry_run_shared_gpu"] = True
         if world == 1 and not args.no_cpu_baseline:
@@ -446,7 +552,7 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            model_line = flownet2c_pass(dev, rank, world, args.model_steps, 2)
+            model_line = flownet2c_pass(dev, rank, world, args.model_steps, args.model_warmup)
         except Exception as exc:   # the hot-path line must not depend on MIOpen finding its kernels
             print(f"[bench] FlowNet2C pass failed: {exc!r}", file=sys.stderr, flush=True)
             model_line = {"error": repr(exc)}

@@ -40,24 +40,28 @@ def _run(cmd):
     return r
 
 
-def build_lib(force=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+def build_lib(force=False, debug=False):
+    """libflownet2_hip.so (the product: public C ABI only) or, with debug=True, libflownet2_hip_debug.so: the same kernels plus
+    the fn2_debug_* entry points and the profiling instantiations they select (csrc/fn2_debug.h; scripts/ and ablation runs)."""
+    objdir = os.path.join(LIBDIR, "debug") if debug else LIBDIR
+    lib = os.path.join(LIBDIR, "libflownet2_hip_debug.so") if debug else LIB
+    os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "flownet2_hip.h"))
     objs, jobs = [], []
     for src in KERNEL_SRCS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or not _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + (["-DFN2_DEBUG_BUILD"] if debug else []) + ["-c", s, "-o", o])
         objs.append(o)
     if jobs:   # the translation units are independent: compile them side by side (each hipcc is single-threaded)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(_run, jobs))
-    if force or not _newer(LIB, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or not _newer(lib, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 def build_modules(force=False):
@@ -93,9 +97,12 @@ def build_modules(force=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", action="store_true", help="only the kernel library")
+    ap.add_argument("--no-debug", action="store_true", help="skip libflownet2_hip_debug.so (profiling entry points)")
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
     print(build_lib(a.force))
+    if not a.no_debug:
+        print(build_lib(a.force, debug=True))
     if not a.lib:
         for o in build_modules(a.force):
             print(o)

@@ -70,9 +70,13 @@ static int corr_forward_impl(const void *in1, const void *in2, void *out, int64_
                                   p.out_bs, p.slope, B, C, H, W, algo - 5000, s);
     }
     if (algo == FN2_CORR_MFMA_F16X2 && !f16x2_ok) return FN2_EUNSUPPORTED;
-    if (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok))
-        return corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
-                                  p.out_bs, p.slope, B, C, H, W, 0, s);
+    if (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok)) {
+        rc = corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
+                                p.out_bs, p.slope, B, C, H, W, 0, s);
+        // automatic selection: a shape the launcher declines (task table / index limits; nothing launched) goes on to the
+        // next kernel, as below
+        if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
+    }
     const bool mfma_ok = corr_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                   stride2) && aligned(in1, 8) && aligned(in2, 8) && aligned(out, 8) &&
                          (out_batch_stride % 2 == 0);
@@ -150,9 +154,11 @@ static int corr_backward_impl(const void *in1, const void *in2, const void *grad
                                    static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, algo - 6000, s);
     }
     if (!debug_variant && algo == FN2_CORR_MFMA_F16X2 && !f16x2_ok) return FN2_EUNSUPPORTED;
-    if (!debug_variant && (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok)))
-        return corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),
-                                   static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, 0, s);
+    if (!debug_variant && (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok))) {
+        rc = corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),
+                                 static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, 0, s);
+        if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
+    }
     const bool mfma_ok = corr_bwd_mfma_f32_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1,
                                                       stride2) &&
                          aligned(in1, 8) && aligned(in2, 8) && aligned(grad_out, 8);
@@ -191,6 +197,7 @@ extern "C" int fn2_correlation_backward(const void *in1, const void *in2, const 
                                        kernel_size, max_displacement, stride1, stride2, FN2_CORR_AUTO, stream);
 }
 
+#ifdef FN2_DEBUG_BUILD   // libflownet2_hip_debug.so only (build.py): the product library exports none of this
 // ---- profiling / ablation instantiations (fn2_debug.h): not part of the public ABI, outputs may be wrong by design
 extern "C" int fn2_debug_correlation_forward(const void *in1, const void *in2, void *out, int dtype, int B, int C, int H, int W,
                                              int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
@@ -215,3 +222,34 @@ extern "C" int fn2_debug_correlation_backward(const void *in1, const void *in2, 
 }
 
 extern "C" void fn2_debug_set_buffer(void *device_ptr) { fn2::corr_f16x2_set_debug_buffer(device_ptr); }
+
+// Streaming-copy probe (bench.py's `copy_ceiling_GBps`): 16 bytes per lane, grid-stride, four independent loads in flight per
+// lane -- the float4 copy MI355X_MICROARCH.md quotes 6.29 TB/s for (read + write bytes).
+typedef float scf4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(scf4 *__restrict__ dst, const scf4 *__restrict__ src, size_t n16, int nt)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt) {
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const scf4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+            const scf4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+            __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+            __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+        }
+    } else {
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const scf4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+            dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+        }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, int nontemporal, void *stream)
+{
+    if (!dst || !src || (bytes % 16) || !fn2::aligned(dst, 16) || !fn2::aligned(src, 16) || blocks < 1) return FN2_EINVAL;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<scf4 *>(dst), static_cast<const scf4 *>(src), bytes / 16, nontemporal);
+    return fn2::launch_status();
+}
+#endif

@@ -512,9 +512,11 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 
 } // namespace hf
 
-static unsigned long long *g_debug_buffer = nullptr;   // profiling only (fn2_debug.h)
+#ifdef FN2_DEBUG_BUILD   // the debug library's timeline buffer (fn2_debug.h); the product library has no global state
+static unsigned long long *g_debug_buffer = nullptr;
 void corr_f16x2_set_debug_buffer(void *p) { g_debug_buffer = static_cast<unsigned long long *>(p); }
 void *corr_f16x2_get_debug_buffer() { return g_debug_buffer; }
+#endif
 
 bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2)
 {
@@ -534,7 +536,11 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     a.in1 = in1; a.in2 = in2; a.out = out; a.out_bs = out_bs; a.slope = slope;
     a.fC = (float)C; a.rC = 1.0f / (float)C;
     a.B = B; a.C = C; a.H = H; a.W = W;
+#ifdef FN2_DEBUG_BUILD
     a.dbg = variant == 64 ? g_debug_buffer : nullptr;
+#else
+    a.dbg = nullptr;
+#endif
     const int HL = H / 2, NRG = (HL + 3) / 4;
     if (2 * NRG * hf::NU > hf::MAX_TAB) return FN2_EUNSUPPORTED;
     // table of the (py, rg, u) combinations of one batch item: those whose B rows 4rg - 10 + 4u .. +3 meet [0, HL) first
@@ -562,7 +568,10 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
     const int G = per_stream < 32 ? (int)per_stream : 32;
 #define FN2_HF(V) case V: hipLaunchKernelGGL((hf::corr_fwd_f16x2<V>), dim3(8u * G), dim3(1024), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HF(0) FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112) FN2_HF(4096)
+        FN2_HF(0)
+#ifdef FN2_DEBUG_BUILD   // profiling instantiations
+        FN2_HF(1) FN2_HF(2) FN2_HF(4) FN2_HF(8) FN2_HF(16) FN2_HF(32) FN2_HF(6) FN2_HF(24) FN2_HF(25) FN2_HF(38) FN2_HF(64) FN2_HF(128) FN2_HF(256) FN2_HF(512) FN2_HF(1024) FN2_HF(1536) FN2_HF(2048) FN2_HF(2112) FN2_HF(4096)
+#endif
     default: return FN2_EINVAL;
     }
 #undef FN2_HF

@@ -673,14 +673,21 @@ int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, f
     a.NRG = (H / 2 + 3) / 4; a.NCGR = C / hb::CG;
     a.nflip = 2; a.flip0 = 0;
     a.fC = (float)C; a.rC = 1.0f / (float)C;
+#ifdef FN2_DEBUG_BUILD
     a.dbg = (variant & 64) ? static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer()) : nullptr;
+#else
+    a.dbg = nullptr;
+#endif
     const long ntasks = 2L * B * 2 * a.NRG * a.NCGR;
     if (ntasks == 0) return FN2_OK;
     if (ntasks > 0x3fffffffL) return FN2_EINVAL;
     const unsigned grid = ntasks < 256 ? (unsigned)ntasks : 256u;   // persistent: one workgroup per CU
 #define FN2_HB(V) case V: hipLaunchKernelGGL((hb::corr_bwd_f16x2<V>), dim3(grid), dim3(hb::NWAVES * 64), 0, s, a); return launch_status();
     switch (variant) {
-        FN2_HB(0) FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31) FN2_HB(64) FN2_HB(256) FN2_HB(65) FN2_HB(66) FN2_HB(68) FN2_HB(72) FN2_HB(80)
+        FN2_HB(0)
+#ifdef FN2_DEBUG_BUILD   // profiling instantiations
+        FN2_HB(1) FN2_HB(2) FN2_HB(4) FN2_HB(8) FN2_HB(16) FN2_HB(6) FN2_HB(24) FN2_HB(31) FN2_HB(64) FN2_HB(256) FN2_HB(65) FN2_HB(66) FN2_HB(68) FN2_HB(72) FN2_HB(80)
+#endif
     default: return FN2_EINVAL;
     }
 #undef FN2_HB

@@ -7,6 +7,7 @@
 //                                   4 no stores, 8 no operand reads, 16 no split / LDS staging writes)
 //   backward variants: 100 + v      instantiations of correlation_mfma_bwd.hip
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -27,6 +28,9 @@ int fn2_debug_resample2d_backward(const float *img, const int64_t *img_strides, 
                                   int kernel_size, int bilinear, int flags, void *stream);
 /* device buffer (>= 64 KB) that forward variant 5064 dumps its s_memtime stamps into; NULL = none */
 void fn2_debug_set_buffer(void *device_ptr);
+/* float4 grid-stride device-to-device copy of `bytes` (multiple of 16) with `blocks` workgroups of 256 lanes: the streaming
+ * ceiling bench.py reports next to the 8 TB/s spec peak */
+int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, int nontemporal, void *stream);
 #ifdef __cplusplus
 }
 #endif

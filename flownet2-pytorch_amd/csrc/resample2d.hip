@@ -778,6 +778,7 @@ extern "C" int fn2_resample2d_forward(const float *img, const int64_t *img_strid
     return resample2d_forward_impl(img, img_strides, flow, out, B, C, Hi, Wi, H, W, kernel_size, bilinear != 0 ? 1 : 0, stream);
 }
 
+#ifdef FN2_DEBUG_BUILD
 extern "C" int fn2_debug_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
                                             int B, int C, int Hi, int Wi, int H, int W,
                                             int kernel_size, int bilinear, int flags, void *stream)
@@ -785,6 +786,7 @@ extern "C" int fn2_debug_resample2d_forward(const float *img, const int64_t *img
     return resample2d_forward_impl(img, img_strides, flow, out, B, C, Hi, Wi, H, W, kernel_size,
                                    (bilinear != 0 ? 1 : 0) | (flags & ~0xff), stream);
 }
+#endif
 
 static int resample2d_backward_impl(const float *img, const int64_t *img_strides, const float *flow,
                                     const float *grad_out, float *grad_img, float *grad_flow,
@@ -846,6 +848,7 @@ extern "C" int fn2_resample2d_backward(const float *img, const int64_t *img_stri
                                     bilinear != 0 ? 1 : 0, stream);
 }
 
+#ifdef FN2_DEBUG_BUILD
 extern "C" int fn2_debug_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
                                              const float *grad_out, float *grad_img, float *grad_flow,
                                              int B, int C, int Hi, int Wi, int H, int W,
@@ -854,6 +857,7 @@ extern "C" int fn2_debug_resample2d_backward(const float *img, const int64_t *im
     return resample2d_backward_impl(img, img_strides, flow, grad_out, grad_img, grad_flow, B, C, Hi, Wi, H, W, kernel_size,
                                     (bilinear != 0 ? 1 : 0) | (flags & ~0xff), stream);
 }
+#endif
 
 extern "C" int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, float div_flow,
                                       int B, int C, int H, int W, int bilinear, void *stream)

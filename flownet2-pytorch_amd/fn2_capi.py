@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libflownet2_hip.so")
+DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libflownet2_hip_debug.so")   # same kernels + fn2_debug_* (csrc/fn2_debug.h)
 
 FN2_F32, FN2_F16, FN2_F64 = 0, 1, 2
 FN2_CORR_AUTO, FN2_CORR_DIRECT, FN2_CORR_MFMA_F32, FN2_CORR_MFMA_BF16X3, FN2_CORR_MFMA_F16X2 = 0, 1, 2, 3, 4
@@ -21,11 +22,13 @@ EXPORTS = [
     "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe",
 ]
 
-# profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design
+# profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design; exported by
+# libflownet2_hip_debug.so only
 DEBUG_EXPORTS = ["fn2_debug_correlation_forward", "fn2_debug_correlation_backward", "fn2_debug_set_buffer",
-                 "fn2_debug_resample2d_forward", "fn2_debug_resample2d_backward"]
+                 "fn2_debug_resample2d_forward", "fn2_debug_resample2d_backward", "fn2_debug_stream_copy"]
 
 _lib = None
+_dbg = None
 
 
 def lib():
@@ -40,10 +43,25 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.fn2_strerror.restype = ctypes.c_char_p
         _lib.fn2_strerror.argtypes = [ctypes.c_int]
-        for name in EXPORTS[1:] + DEBUG_EXPORTS:
+        for name in EXPORTS[1:]:
             getattr(_lib, name).restype = ctypes.c_int
         _lib.fn2_multiscale_workspace_bytes.restype = ctypes.c_size_t
     return _lib
+
+
+def debug_lib():
+    """libflownet2_hip_debug.so: the product kernels plus the profiling instantiations (scripts/, ablations)."""
+    global _dbg
+    if _dbg is None:
+        import torch  # noqa: F401
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise RuntimeError(f"{DEBUG_LIB_PATH} not found: run `python flownet2-pytorch_amd/build.py`")
+        _dbg = ctypes.CDLL(DEBUG_LIB_PATH)
+        _dbg.fn2_strerror.restype = ctypes.c_char_p
+        for name in EXPORTS[1:] + DEBUG_EXPORTS:
+            getattr(_dbg, name).restype = ctypes.c_int
+        _dbg.fn2_debug_set_buffer.restype = None
+    return _dbg
 
 
 def check(rc, what):
@@ -79,7 +97,7 @@ def correlation_forward(in1, in2, pad, k, md, s1, s2, algo=FN2_CORR_AUTO, out=No
     if out is None:
         out = torch.empty((B, nOut, oH, oW), dtype=in1.dtype, device=in1.device)
     # algo >= 100: profiling instantiations, only reachable through the debug entry point
-    fn, what = ((lib().fn2_debug_correlation_forward, "fn2_debug_correlation_forward") if algo >= 100 else
+    fn, what = ((debug_lib().fn2_debug_correlation_forward, "fn2_debug_correlation_forward") if algo >= 100 else
                 (lib().fn2_correlation_forward_ex, "fn2_correlation_forward_ex"))
     with torch.cuda.device_of(in1):
         check(fn(_p(in1), _p(in2), _p(out), _dtype_code(in1), B, C, H, W, pad, k, md, s1, s2, algo, _stream(in1)), what)
@@ -105,7 +123,7 @@ def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO,
     import torch
     B, C, H, W = in1.shape
     g1, g2 = out if out is not None else (torch.empty_like(in1), torch.empty_like(in2))
-    fn, what = ((lib().fn2_debug_correlation_backward, "fn2_debug_correlation_backward") if algo >= 100 else
+    fn, what = ((debug_lib().fn2_debug_correlation_backward, "fn2_debug_correlation_backward") if algo >= 100 else
                 (lib().fn2_correlation_backward_ex, "fn2_correlation_backward_ex"))
     with torch.cuda.device_of(in1):
         check(fn(_p(in1), _p(in2), _p(gout), _p(g1), _p(g2), _dtype_code(in1), B, C, H, W, pad, k, md, s1, s2, algo,

@@ -29,7 +29,7 @@ class BucketedGradAllReduce:
         self.device = params[0].device
         self.on_gpu = self.device.type == "cuda"
         # ---- buckets of flat storage, filled in reverse order of registration
-        self.buckets, self._bucket_of = [], {}
+        self.buckets, self._bucket_of, self._home = [], {}, {}
         cur, cur_bytes = [], 0
         for p in reversed(params):
             if p.dtype != torch.float32 or p.device != self.device:
@@ -52,8 +52,10 @@ class BucketedGradAllReduce:
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=torch.float32, device=self.device)
         off = 0
         for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)     # the gradient lives in the bucket
+            view = flat[off:off + p.numel()].view_as(p)
+            p.grad = view                                     # the gradient lives in the bucket
             self._bucket_of[p] = len(self.buckets)
+            self._home[p] = (view, view.data_ptr())           # cached: the hook runs once per parameter and step
             off += p.numel()
         self.buckets.append({"flat": flat, "params": plist})
 
@@ -82,25 +84,17 @@ class BucketedGradAllReduce:
 
     def _on_grad(self, p):
         i = self._bucket_of[p]
-        if p.grad.data_ptr() != self._grad_ptr(p):     # something replaced .grad (e.g. set_to_none): re-home it
-            view = self._view(p)
+        view, ptr = self._home[p]
+        if p.grad.data_ptr() != ptr:                   # something replaced .grad (e.g. set_to_none): re-home it
             view.copy_(p.grad)
             p.grad = view
         self._pending[i] -= 1
         if self._pending[i] == 0:
             self._launch(i)
 
-    def _view(self, p):
-        b = self.buckets[self._bucket_of[p]]
-        off = 0
-        for q in b["params"]:
-            if q is p:
-                return b["flat"][off:off + p.numel()].view_as(p)
-            off += q.numel()
-        raise KeyError("parameter not in its bucket")
-
     def _grad_ptr(self, p):
-        return self._view(p).data_ptr()
+        """Address of the parameter's home in its bucket."""
+        return self._home[p][1]
 
     def finish(self):
         """After backward, before the optimizer: wait for the collectives, average.  Buckets whose hooks never completed (a

@@ -59,11 +59,23 @@ enum {
                                 v_mfma_f32_16x16x32_bf16, fp32 accumulate -- fp32-class accuracy (same error vs fp64 as
                                 FN2_CORR_MFMA_F32).  Forward additionally needs W <= 64, C % 32 == 0, even md/2;
                                 backward needs md/2 == 10, C % 64 == 0, W % 4 == 0, 16 B aligned tensors */
-    FN2_CORR_MFMA_F16X2 = 4  /* forward only: fp32 operands split ONCE per staged value into two f16 terms (round to nearest),
-                                3 partial products on v_mfma_f32_16x16x32_f16, fp32 accumulate; outputs an operand of
-                                magnitude >= 65520 touches are recomputed in plain fp32.  Operand representation error
-                                max(2^-22 |x|, 2^-25): fp32-class.  Needs md == 20, W % 8 == 0, W <= 64, C % 32 == 0,
-                                16 B aligned tensors.  What FN2_CORR_AUTO picks for FlowNetC's cost volume. */
+    FN2_CORR_MFMA_F16X2 = 4  /* forward AND backward (csrc/correlation_f16x2*.hip, csrc/f16x2_split.h): every fp32 operand x of a
+                                task is written as x * 2^k = h + l with two f16 terms (round to nearest), 3 partial products on
+                                v_mfma_f32_16x16x32_f16, fp32 accumulation; the power-of-two scale 2^k -- one per operand and
+                                task, from the mean binary exponent of a 128..256-element sample of the operand -- is exact and
+                                is removed exactly together with the 1/C.
+                                Error bound per operand, relative to the operand's typical (geometric-mean) magnitude m:
+                                max(2^-22 |x| / m, 2^-27), at ANY input magnitude (checked from 2^-27 to 2^13 and on a real
+                                training gradient, tests/test_gpu_parity.py magnitude sweeps): fp32-class sums, measured
+                                0.65x the fp32 MFMA kernel's error against fp64.  Operands above 16384 m do not fit the
+                                scaled f16; the outputs they touch are recomputed by a plain fp32 fma chain (slow, exact
+                                semantics incl. inf / nan).  Operands far BELOW m (< 2^-27 m) lose relative accuracy:
+                                block scaling is not scale-invariant within a task, unlike the reference's fp32 products.
+                                Needs f32, k = 1, s1 = 1, s2 = 2, pad == md == 20, even H, W % 8 == 0, W <= 64,
+                                C % 64 == 0, 16 B aligned tensors (forward also out_batch_stride % 4 == 0); the forward
+                                launcher additionally declines H > 512 and B x tasks-per-item >= 65536.
+                                What FN2_CORR_AUTO picks, forward and backward, for FlowNetC's cost volume; shapes the
+                                launcher declines go on to FN2_CORR_MFMA_F32 / FN2_CORR_DIRECT under AUTO. */
 };
 /* any other algo value: FN2_EINVAL */
 
@@ -125,8 +137,11 @@ int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *gr
  *   flow : B x 2 x H x W contiguous (channel 0 = dx, 1 = dy)
  *   out  : B x C x H x W contiguous, fully written
  * kernel_size >= 1.  For kernel_size > 1 the reference sums the four corners over a kernel_size x kernel_size window of
- * offsets (:54-61) without a bounds test, i.e. it reads past its tensors near the lower/right border; here the shifted
- * indices are clamped to the image: identical wherever the reference is defined.
+ * offsets (:54-61) without a bounds test: near the lower / right border its shifted addresses run into the next row, the
+ * next channel or past the tensor (the backward pass accumulates there).  Here the shifted indices are clamped to the image
+ * instead: results are the reference's for every sample whose window stays inside, i.e. yT + ky <= Hi - 1 and
+ * xR + kx <= Wi - 1 for all window offsets; at the border they differ from the reference's wrapped reads even where those
+ * still fall inside its allocation.  FlowNet2 only uses kernel_size 1 (models.py:48-51), where there is no difference.
  * FN2_EINVAL for kernel_size < 1. */
 int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const float *flow, float *out,
                            int B, int C, int Hi, int Wi, int H, int W,

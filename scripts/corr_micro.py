@@ -21,8 +21,9 @@ ap.add_argument("--bwd", default="")
 ap.add_argument("--batch", type=int, default=40)
 ap.add_argument("--lib", default="", help="A/B runs: load this build of libflownet2_hip.so instead of the in-tree one")
 a = ap.parse_args()
-if a.lib:
+if a.lib:   # an A/B build (scripts/build_ablations.sh): used for the public AND the debug entry points if it exports them
     fn2_capi.LIB_PATH = os.path.abspath(a.lib)
+    fn2_capi.DEBUG_LIB_PATH = os.path.abspath(a.lib)
 B, C, H, W = (int(v) for v in a.shape.split(","))
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -33,8 +34,8 @@ out = torch.empty(B, D * D, H, W, device=dev)
 ref = None
 res = {}
 dbg = torch.zeros(256 * 2 * 16, dtype=torch.int64, device=dev)
-fn2_capi.lib().fn2_debug_set_buffer.restype = None
-fn2_capi.lib().fn2_debug_set_buffer(fn2_capi._p(dbg))
+if any(int(v) >= 100 for v in (a.algos + "," + a.bwd).split(",") if v):
+    fn2_capi.debug_lib().fn2_debug_set_buffer(fn2_capi._p(dbg))
 for algo in (int(v) for v in a.algos.split(",")):
     try:
         for _ in range(3):

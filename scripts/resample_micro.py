@@ -3,7 +3,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
 import torch, fn2_capi
-lib = fn2_capi.lib()
+lib = fn2_capi.debug_lib()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 B, C, H, W = 8, 3, 384, 512

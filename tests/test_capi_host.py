@@ -30,6 +30,19 @@ def test_header_symbols_exported():
     assert lib.fn2_abi_version() == 1
 
 
+def test_product_library_exports_only_the_public_abi():
+    """The profiling entry points (csrc/fn2_debug.h) -- among them the one that sets a process-global timeline buffer -- live in
+    libflownet2_hip_debug.so; the product library exports exactly the fn2_* symbols include/flownet2_hip.h declares
+    ('no global mutable state')."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", fn2_capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("fn2_")})
+    assert exported == declared_symbols(), set(exported) ^ set(declared_symbols())
+    dbg = fn2_capi.debug_lib()
+    for n in fn2_capi.DEBUG_EXPORTS + fn2_capi.EXPORTS:
+        assert hasattr(dbg, n), n
+
+
 def test_output_shape_matches_reference_formula():
     # correlation_cuda.cc:19-34
     assert fn2_capi.correlation_output_shape(48, 64, 20, 1, 20, 1, 2) == (441, 48, 64)

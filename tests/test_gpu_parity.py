@@ -1132,3 +1132,25 @@ def test_correlation_f16x2_scale_sample_misses(dev):
     f1, f2 = _corr_bwd_fp64(ad, bd, gd)
     g1, g2 = fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
     assert float((g1.double() - f1).abs().max()) <= 1e-9 and float((g2.double() - f2).abs().max()) <= 1e-9
+
+
+def test_correlation_auto_falls_back_when_f16x2_declines(dev):
+    """Shapes inside corr_f16x2_applicable's domain that its launcher declines (task table: H > 512; 16-bit task index:
+    B x tasks-per-item >= 65536) must still work through FN2_CORR_AUTO / fn2_correlation_forward: they go on to
+    the fp32 MFMA / general kernels; the explicit selector reports FN2_EUNSUPPORTED."""
+    import fn2_capi
+    g = torch.Generator().manual_seed(41)
+    for shape in ((1, 64, 1024, 64), (10940, 64, 2, 8)):
+        a = torch.randn(shape, generator=g).to(dev)
+        b = torch.randn(shape, generator=g).to(dev)
+        with pytest.raises(RuntimeError):
+            fn2_capi.correlation_forward(a, b, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+        out = fn2_capi.correlation_forward(a, b, 20, 1, 20, 1, 2)
+        ref = fn2_capi.correlation_forward(a, b, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+        assert float((out - ref).abs().max()) <= 2e-6
+        del out, ref
+        if shape[0] == 1:   # backward: the f16x2 launcher has no such limits, AUTO stays on it
+            go = torch.randn(shape[0], 441, shape[2], shape[3], generator=g).to(dev)
+            g1, g2 = fn2_capi.correlation_backward(a, b, go, 20, 1, 20, 1, 2)
+            r1, r2 = fn2_capi.correlation_backward(a, b, go, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+            assert float((g1 - r1).abs().max()) <= 1e-5 and float((g2 - r2).abs().max()) <= 1e-5
