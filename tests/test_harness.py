@@ -214,3 +214,48 @@ def test_flownet2_full_stack_inference(dev):
     with torch.no_grad():
         out16 = half(inputs.half())
     assert out16.dtype == torch.float16 and torch.isfinite(out16).all()
+
+
+@pytest.mark.gpu
+def test_flownet2_hip_layers_vs_torch_stand_ins(dev):
+    """Second half of the transitive pin of SURVEY 8 row (g) (the reference's models cannot travel to the GPU box):
+    tests/test_harness_pin.py shows harness.FlowNet2 == the reference's models.FlowNet2 when both use plain-torch layers (CPU);
+    here the SAME harness network runs on the GPU once with the HIP Correlation / Resample2d / ChannelNorm and once with
+    those plain-torch layers: the flows agree, so the HIP layers inside the reference's architecture give the reference's
+    result."""
+    from harness.flownet2 import FlowNet2
+    from harness.train import synthetic_batch
+
+    class TorchResample(torch.nn.Module):
+        def forward(self, img, flow):
+            B, _, H, W = flow.shape
+            ys, xs = torch.meshgrid(torch.arange(H, dtype=flow.dtype, device=flow.device),
+                                    torch.arange(W, dtype=flow.dtype, device=flow.device), indexing="ij")
+            gx = (xs + flow[:, 0]) * (2.0 / (W - 1)) - 1.0
+            gy = (ys + flow[:, 1]) * (2.0 / (H - 1)) - 1.0
+            return F.grid_sample(img, torch.stack((gx, gy), -1), mode="bilinear", padding_mode="border", align_corners=True)
+
+    class TorchNorm(torch.nn.Module):
+        def forward(self, x):
+            return x.pow(2).sum(1, keepdim=True).sqrt()
+
+    class TorchCorr(torch.nn.Module):
+        def forward(self, a, b):
+            return _corr_torch(a, b)
+
+    torch.manual_seed(8)
+    net = FlowNet2().to(dev).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)                                # keeps the random-init stack's flows inside the image
+    inputs, _ = synthetic_batch(2, 128, 192, dev, seed=9)
+    hip = net(inputs).detach()                         # grad mode: the separate HIP modules
+    saved = (net.flownetc.corr, net.channelnorm, net.resample1, net.resample2, net.resample3, net.resample4)
+    net.flownetc.corr, net.channelnorm = TorchCorr(), TorchNorm()
+    net.resample1 = net.resample2 = net.resample3 = net.resample4 = TorchResample()
+    try:
+        ref = net(inputs).detach()
+    finally:
+        net.flownetc.corr, net.channelnorm, net.resample1, net.resample2, net.resample3, net.resample4 = saved
+    scale = max(float(ref.abs().max()), 1e-6)
+    assert float((hip - ref).abs().max()) <= 1e-3 * scale, (float((hip - ref).abs().max()), scale)
