@@ -86,9 +86,11 @@ template <int VAR>
 __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    // ka + kb of the current task's operand scales (f16x2_split.h): written by staging wave 0 before the task's first barrier,
-    // read by the matrix waves after it (they undo the scales in the epilogue)
-    __shared__ int scl_ksum;
+    // scale exponents (f16x2_split.h).  [0] = ka + kb of the CURRENT task: written by staging wave 0 before the task's first
+    // barrier, read by the matrix waves after it (they undo the scales in the epilogue).  [1], [2] = ka, kb of the NEXT task:
+    // written by staging wave 0 -- the only wave that samples after a workgroup's first task -- while the matrix waves scatter,
+    // read by the other staging waves after the barrier that follows.
+    __shared__ int scl_k[3];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,7 +171,11 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
         const int kx_mm = -ksum - lgC, kx_ex = -lgC;   // matrix-core sums / sums of the fp32 fallback
         auto finish = [&](f4 val, int kx) {
 #pragma unroll
+#ifdef FN2_ABL_MULEPI   // timing ablation: multiply by 2^kx (valid for -126 <= kx <= 127 only)
+            for (int e = 0; e < 4; ++e) val[e] = val[e] * __builtin_bit_cast(float, (unsigned)(127 + kx) << 23);
+#else
             for (int e = 0; e < 4; ++e) val[e] = __builtin_ldexpf(val[e], kx);
+#endif
             if (!pow2) { val[0] /= f; val[1] /= f; val[2] /= f; val[3] /= f; }
             if (p.slope != 1.0f) {
 #pragma unroll
@@ -279,11 +285,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             }
         };
         // Operand sample of a task: ONE 16-byte load per lane and tile straight from global memory -- lane l: channel l C / 64, tile
-        // row l & 3, 4 pixels at a pseudo-random column -- 256 values per tile.  EVERY staging wave loads the same 256 + 256 values
-        // and derives the same two exponents: no exchange between the waves, no barrier.  (One load instruction per tile because
-        // a load costs the CU's vector-memory path 16 cycles whatever its width, and that path paces the steps: with four dword
-        // loads per lane and tile the kernel was 1.6 us slower.)  Requested two steps before the task starts, ahead of its first
-        // operand loads, so that they return first; evaluated while the matrix waves scatter the previous task's accumulators.
+        // row l & 3, 4 pixels at a pseudo-random column -- 256 values per tile.  For a workgroup's FIRST task every
+        // staging wave loads the same 256 + 256 values and derives the same two exponents (no exchange, no barrier before the
+        // first operands are converted); afterwards staging wave 0 alone samples -- two steps before the task starts, ahead of its
+        // first operand loads -- and publishes the exponents through LDS while the matrix waves scatter the previous task's
+        // accumulators.  (The vector-memory path paces the steps, and these loads touch 64 cache lines each: issued by all 8
+        // waves they cost 0.8 us per launch, with four dword loads per lane and tile 1.6 us more.)
         struct Samp { u4 a, b; };
         auto sample_issue = [&](const Task &tk, Samp &S) {
             int ln = lane;
@@ -294,8 +301,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             const int ila = 4 * tk.rg + r, ilb = 4 * tk.rg - DR + 4 * tk.u + r;
             const unsigned oa = ila < HL ? (unsigned)((c * HW + (long)(2 * ila + tk.py) * p.W + x) * 4) : 0x80000000u;
             const unsigned ob = (ilb >= 0 && ilb < HL) ? (unsigned)((c * HW + (long)(2 * ilb + tk.py) * p.W + x) * 4) : 0x80000000u;
+#ifdef FN2_ABL_NOSAMPLELOAD   // timing ablation
+            S.a = (u4)0x3f000000u; S.b = (u4)0x3f000000u; (void)oa; (void)ob;
+#else
             S.a = (VAR & 2) ? (u4)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b128(r1, (int)oa, 0, 0);
             S.b = (VAR & 2) ? (u4)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b128(r2, (int)ob, 0, 0);
+#endif
         };
         auto sample_scales = [&](const Samp &S, int &ka, int &kb) {
             unsigned ta = 0u, tb = 0u;
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             const bool has_next = it + 1 < n_real;
             const int ksum = ka_n + kb_n;
             sc_a = f16s::scale2_from_exp(ka_n); sc_b = f16s::scale2_from_exp(kb_n);
-            if (tid == 0) scl_ksum = ksum;     // (the matrix waves read the previous task's value right after that task's first barrier)
+            if (tid == 0) scl_k[0] = ksum;     // (the matrix waves read the previous task's value right after that task's first barrier)
             stage_write(L0, smem);
             if (it < 2) stamp(2 + 6 * it);
             __syncthreads();
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             }
             // last two steps: the free register sets receive steps 0 and 1 of the next real task (after the last one the
             // offsets are out of range: the loads return zeros without touching memory)
-            if (has_next) sample_issue(get_task(it + 1), SM);
+            if (has_next && wave == 0) sample_issue(get_task(it + 1), SM);
             set_ctx(get_task(has_next ? it + 1 : it), has_next);
             issue_loads(L0, chunk(it + 1, 0));
             stage_write(L1, smem + BUF);
@@ -358,10 +369,14 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
             issue_loads(L1, chunk(it + 1, 1));
             __syncthreads();
             if (it < 2) stamp(3 + 6 * it);
-            // while the matrix waves scatter their accumulators: the next task's scale exponents
-            if (has_next) sample_scales(SM, ka_n, kb_n);
+            // while the matrix waves scatter their accumulators: the next task's scale exponents (wave 0; the others read them)
+            if (has_next && wave == 0) {
+                sample_scales(SM, ka_n, kb_n);
+                if (lane == 0) { scl_k[1] = ka_n; scl_k[2] = kb_n; }
+            }
             __syncthreads();   // the epilogue image is complete
             if (it < 2) stamp(4 + 6 * it);
+            if (has_next && wave != 0) { ka_n = to_sgpr(scl_k[1]); kb_n = to_sgpr(scl_k[2]); }
             store_rows(tk, ksum);
             if (it < 2) stamp(5 + 6 * it);
             __syncthreads();   // ... and has been read: the buffers are free
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
-        const int ksum = to_sgpr(scl_ksum);    // ka + kb of this task's operand scales
+        const int ksum = to_sgpr(scl_k[0]);    // ka + kb of this task's operand scales
         if (it < 2) stamp(2 + 6 * it);
         for (int s = 0; s < nsteps; s += 2) {
             step_dispatch(smem);

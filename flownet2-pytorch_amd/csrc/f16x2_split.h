@@ -12,10 +12,12 @@
 //
 // k places the TYPICAL magnitude of the operand -- the mean binary exponent of the non-zero values of a sample of 256
 // elements spread over the task's operand (all channels of the tile / the gO image of the central displacements), read
-// straight from global memory by one staging wave while the previous task finishes -- at 2^T_GEO:
-//   - values down to 2^-(3 + T_GEO) = 1/32 of the typical magnitude keep >= 22 bits, smaller ones an absolute error of
-//     2^-(25 + T_GEO) = 2^-27 of it: fp32-class sums at any input magnitude;
-//   - values up to 2^(16 - T_GEO) = 16384 x the typical magnitude fit; anything larger makes h infinite, the outputs it
+// straight from global memory by the staging waves while the previous task finishes -- at 2^T_GEO = 1/2, where unit-variance
+// data sit by themselves (the mean exponent of N(0,1) values is -1.4: k = 0, the split of round 2):
+//   - values down to 2^-(3 + T_GEO) = 1/4 of the typical magnitude keep >= 22 bits, smaller ones an absolute error of
+//     2^-(25 + T_GEO) = 2^-24 of it: fp32-class sums at any input magnitude (measured: 0.65 x the fp32 MFMA kernel's error
+//     against fp64 from 2^-27 to 2^13, tests/test_gpu_parity.py);
+//   - values up to 2^(16 - T_GEO) = 131072 x the typical magnitude fit; anything larger makes h infinite, the outputs it
 //     touches come out non-finite and are recomputed by a plain fp32 fma chain (exact_corr / exact_grad: slow, always right).
 // The mean exponent (not the maximum) is used because a single huge element must not push everything else of the tile
 // into the f16 subnormals.  Scaling by a power of two is exact: for operands of unit magnitude the split, the products
@@ -25,7 +27,7 @@
 namespace fn2 {
 namespace f16s {
 
-constexpr int T_GEO = 2;   // the sample's mean exponent lands at 2^2
+constexpr int T_GEO = -1;   // the sample's mean exponent lands at 2^-1
 
 // Two-term split of an (already scaled) pair: h = RNE_f16 of both values (v_cvt_pk_f16_f32), l = RNE_f16 of the exact fp32
 // residuals (v_fma_mix_f32 forms x - h in one instruction): four VALU instructions per pair.  The scale itself is a
@@ -53,6 +55,9 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
 typedef float f2s __attribute__((ext_vector_type(2)));
 typedef float f4s __attribute__((ext_vector_type(4)));
 typedef unsigned long long scale2_t;
+// (A scale of 1 -- unit-magnitude operands, k = 0 -- is multiplied like any other: a uniform branch around the two or four
+// v_pk_mul_f32 of an item measured as slow as the multiplies it skips, it splits the staging loop's basic blocks; a second
+// instantiation of the step loop for k = 0 spilled 66 registers.)
 __device__ __forceinline__ f2s pk_scale(f2s v, scale2_t s2)
 {
 #ifdef FN2_ABL_NOMUL   // timing ablation (scripts/gpu_ablate.sh): results wrong unless k == 0

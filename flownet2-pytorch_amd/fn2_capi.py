@@ -59,7 +59,8 @@ def debug_lib():
         _dbg = ctypes.CDLL(DEBUG_LIB_PATH)
         _dbg.fn2_strerror.restype = ctypes.c_char_p
         for name in EXPORTS[1:] + DEBUG_EXPORTS:
-            getattr(_dbg, name).restype = ctypes.c_int
+            if hasattr(_dbg, name):      # (A/B runs load older builds that lack the newer entry points)
+                getattr(_dbg, name).restype = ctypes.c_int
         _dbg.fn2_debug_set_buffer.restype = None
     return _dbg
 

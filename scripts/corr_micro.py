@@ -19,6 +19,8 @@ ap.add_argument("--shape", default="8,256,48,64")
 ap.add_argument("--md", type=int, default=20)
 ap.add_argument("--bwd", default="")
 ap.add_argument("--batch", type=int, default=40)
+ap.add_argument("--in-scale", type=float, default=1.0, help="multiply in1 / in2 (the block-scaled kernels skip a scale of 1)")
+ap.add_argument("--go-scale", type=float, default=1.0, help="multiply gradOutput")
 ap.add_argument("--lib", default="", help="A/B runs: load this build of libflownet2_hip.so instead of the in-tree one")
 a = ap.parse_args()
 if a.lib:   # an A/B build (scripts/build_ablations.sh): used for the public AND the debug entry points if it exports them
@@ -27,8 +29,8 @@ if a.lib:   # an A/B build (scripts/build_ablations.sh): used for the public AND
 B, C, H, W = (int(v) for v in a.shape.split(","))
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-in1 = torch.randn(B, C, H, W, generator=g).to(dev)
-in2 = torch.randn(B, C, H, W, generator=g).to(dev)
+in1 = (a.in_scale * torch.randn(B, C, H, W, generator=g)).to(dev)
+in2 = (a.in_scale * torch.randn(B, C, H, W, generator=g)).to(dev)
 D = 2 * (a.md // 2) + 1
 out = torch.empty(B, D * D, H, W, device=dev)
 ref = None
@@ -93,7 +95,7 @@ for algo in (int(v) for v in a.algos.split(",")):
             for w in range(8):
                 print("   wg", sl, "wave", w, [int(v) - t0 if v > 0 else None for v in st[sl, w]])
 if a.bwd:
-    gout = torch.randn(B, D * D, H, W, generator=g).to(dev)
+    gout = (a.go_scale * torch.randn(B, D * D, H, W, generator=g)).to(dev)
     refb = None
     for algo in (int(v) for v in a.bwd.split(",")):
         try:

@@ -9,7 +9,7 @@ for rep in $(seq 1 ${REPS:-3}); do
   for n in ${LIBS:-r2} HEAD; do
     L=scripts/ab/libflownet2_hip_$n.so; [ $n = HEAD ] && L=flownet2-pytorch_amd/lib/libflownet2_hip.so
     echo "== $n" >> $OUT/ab.log
-    timeout 300 python scripts/corr_micro.py --algos 4 --bwd 4 --lib $L 2>/dev/null | grep -v "^{" >> $OUT/ab.log
+    timeout 300 python scripts/corr_micro.py --algos 4 --bwd 4 --lib $L ${MICRO_ARGS:-} 2>/dev/null | grep -v "^{" >> $OUT/ab.log
   done
 done
 python - <<'PY'
