@@ -33,6 +33,7 @@ cases = {
     "leaky_relu(N(0,1))": (F.leaky_relu(torch.randn(B, C, H, W, generator=g), 0.1), F.leaky_relu(torch.randn(B, C, H, W, generator=g), 0.1)),
     "N(0,1)*100": (100 * torch.randn(B, C, H, W, generator=g), 100 * torch.randn(B, C, H, W, generator=g)),
     "N(0,1)*1e-3": (1e-3 * torch.randn(B, C, H, W, generator=g), 1e-3 * torch.randn(B, C, H, W, generator=g)),
+    "N(0,1)*1e-6 x N(0,1)*1e-8": (1e-6 * torch.randn(B, C, H, W, generator=g), 1e-8 * torch.randn(B, C, H, W, generator=g)),
     "lognormal magnitudes": (torch.randn(B, C, H, W, generator=g) * torch.exp(3 * torch.randn(B, C, H, W, generator=g)),
                              torch.randn(B, C, H, W, generator=g) * torch.exp(3 * torch.randn(B, C, H, W, generator=g))),
 }
