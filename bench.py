@@ -213,9 +213,22 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
         tr.criterion(tr.model(inputs), target)[0].backward()
         tr.reducer.finish()
 
-    t_train = dist_utils.max_over_ranks(time_steps(lambda: tr.train_step(inputs, target), steps, warmup, dev), device=dev)
-    t_fb = dist_utils.max_over_ranks(time_steps(fwd_bwd, steps, warmup, dev), device=dev)
-    t_inf = dist_utils.max_over_ranks(time_steps(lambda: tr.infer(inputs), steps, warmup, dev), device=dev)
+    def phase(fn):
+        """One timed phase on every rank.  A rank that fails locally says so through the same MAX all-reduce the others are
+        about to enter, so that all ranks leave the pass together instead of blocking in the next collective.
+        (A failure INSIDE a phase's own gradient all-reduce still needs the watchdog / the launcher to end the job.)"""
+        try:
+            t, err = fn(), None
+        except Exception as exc:
+            t, err = float("inf"), exc
+        t = dist_utils.max_over_ranks(t, device=dev)
+        if t == float("inf"):
+            raise RuntimeError(f"FlowNet2C pass failed on a rank: {err!r}" if err is not None else "FlowNet2C pass failed on another rank")
+        return t
+
+    t_train = phase(lambda: time_steps(lambda: tr.train_step(inputs, target), steps, warmup, dev))
+    t_fb = phase(lambda: time_steps(fwd_bwd, steps, warmup, dev))
+    t_inf = phase(lambda: time_steps(lambda: tr.infer(inputs), steps, warmup, dev))
     pairs = IMG["B"] * world
     # BASELINE.json configs[3]: the full FlowNet2 stack (CSS + SD + fusion, 162.5 M parameters), inference, fp32 and with fp16
     # convolution stacks (the custom layers keep fp32 operands); rank-local, no collective
