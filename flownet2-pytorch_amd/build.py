@@ -100,9 +100,14 @@ def main():
     ap.add_argument("--no-debug", action="store_true", help="skip libflownet2_hip_debug.so (profiling entry points)")
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
-    print(build_lib(a.force))
-    if not a.no_debug:
-        print(build_lib(a.force, debug=True))
+    if a.no_debug:
+        print(build_lib(a.force))
+    else:   # the two libraries share no object files: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            futs = [pool.submit(build_lib, a.force, False), pool.submit(build_lib, a.force, True)]
+            for f in futs:
+                print(f.result())
     if not a.lib:
         for o in build_modules(a.force):
             print(o)
