@@ -69,6 +69,12 @@ static int corr_forward_impl(const void *in1, const void *in2, void *out, int64_
         return corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),
                                   p.out_bs, p.slope, B, C, H, W, algo - 5000, s);
     }
+    // half tensors on FlowNetC's configuration: the single-product f16 kernel (correlation_f16_fwd.hip); AUTO or the f16x2 selector
+    if (!debug_variant && (algo == FN2_CORR_AUTO || algo == FN2_CORR_MFMA_F16X2) &&
+        corr_f16_fwd_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)) {
+        rc = corr_forward_f16(in1, in2, out, p.out_bs, p.slope, B, C, H, W, s);
+        if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
+    }
     if (algo == FN2_CORR_MFMA_F16X2 && !f16x2_ok) return FN2_EUNSUPPORTED;
     if (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok)) {
         rc = corr_forward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<float *>(out),

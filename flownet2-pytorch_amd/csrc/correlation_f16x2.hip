@@ -51,28 +51,6 @@ using f16s::wave_sum;
 
 struct LoadSet { u4 a[2][2], b[2][2]; };   // one step of one lane: [slot][half] x 16 B of the A tile and of the B tile
 
-// A task = (batch item n, y parity, row group rg of 4 lattice rows, B row block u).  "Real" tasks have B rows inside the
-// image; the others only write zeros.  Tasks are numbered item-major, separately for the two kinds; the (py, rg, u) of the
-// k-th task of a kind within an item comes from a table the launcher puts into the kernel arguments (all scalar work).
-struct Task { int n, py, rg, u, real; };
-
-__device__ __forceinline__ Task decode_task(const Args &p, bool real, int k)
-{
-    const unsigned per = real ? (unsigned)p.R_item : (unsigned)p.P_item;
-    const unsigned n = __umulhi((unsigned)k, real ? p.magic_r : p.magic_p);   // k / per (exact for k < 2^16, checked by the launcher)
-    const unsigned r = (unsigned)k - n * per;
-    // dword loads with a wave-uniform index: scalar loads from the kernel-argument segment
-    const unsigned i = __builtin_amdgcn_readfirstlane((real ? 0u : (unsigned)p.R_item) + r);
-    const unsigned e = (p.tab[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
-    Task t;
-    t.real = real ? 1 : 0;
-    t.n = __builtin_amdgcn_readfirstlane((int)n);
-    t.u = __builtin_amdgcn_readfirstlane((int)(e & 7u));
-    t.py = __builtin_amdgcn_readfirstlane((int)((e >> 3) & 1u));
-    t.rg = __builtin_amdgcn_readfirstlane((int)(e >> 4));
-    return t;
-}
-
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no global stores, 8 no operand reads,
 //      16 no split / LDS staging writes, 32 no epilogue (no scatter, no stores), 64 s_memtime stamps dumped over the output,
 //      4096 every step loads channel chunk 0 (all loads hit the L2: measured no faster -- misses do not pace the steps)
@@ -556,28 +534,9 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
 #else
     a.dbg = nullptr;
 #endif
-    const int HL = H / 2, NRG = (HL + 3) / 4;
-    if (2 * NRG * hf::NU > hf::MAX_TAB) return FN2_EUNSUPPORTED;
-    // table of the (py, rg, u) combinations of one batch item: those whose B rows 4rg - 10 + 4u .. +3 meet [0, HL) first
-    int R = 0, P = 0;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int py = 0; py < 2; ++py)
-            for (int g = 0; g < NRG; ++g)
-                for (int u = 0; u < hf::NU; ++u) {
-                    const int ib0 = 4 * g - hf::DR + 4 * u;
-                    const bool real = ib0 + 3 >= 0 && ib0 < HL;
-                    if (real != (pass == 0)) continue;
-                    const unsigned e = (unsigned)((g << 4) | (py << 3) | u), i = (unsigned)(R + P);
-                    a.tab[i >> 1] = (i & 1u) ? (a.tab[i >> 1] | (e << 16)) : e;
-                    if (real) ++R; else ++P;
-                }
-    a.R_item = R; a.P_item = P;
-    a.magic_r = R ? (unsigned)((0x100000000ull + R - 1) / R) : 0u;
-    a.magic_p = P ? (unsigned)((0x100000000ull + P - 1) / P) : 0u;
-    if ((long)B * (R > P ? R : P) >= 65536) return FN2_EUNSUPPORTED;   // the magic-number division is exact below 2^16
-    const long ntasks = (long)B * (R + P);
+    const long ntasks = hf::build_task_table(a, B, H);
+    if (ntasks < 0) return (int)ntasks;
     if (ntasks == 0) return FN2_OK;
-    if (ntasks > 0x3fffffffL) return FN2_EINVAL;
     // persistent grid: 8 streams (one per XCD) x G workgroups, one workgroup per CU
     const long per_stream = (ntasks + 7) / 8;
     const int G = per_stream < 32 ? (int)per_stream : 32;

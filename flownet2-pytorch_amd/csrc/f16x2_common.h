@@ -34,9 +34,9 @@ static_assert((16 * O_DP + O_SLACK) * O_RS * 4 <= LDS_BYTES, "epilogue image mus
 
 constexpr int MAX_TAB = 768;                      // tasks per batch item the kernel-argument table holds (H <= 512)
 
-struct Args {
-    const float *in1, *in2;
-    float *out;
+template <class T> struct ArgsT {
+    const T *in1, *in2;
+    T *out;
     long out_bs;     // elements between batch items of `out`
     float slope;     // fused LeakyReLU slope (1 = none)
     float fC, rC;    // (float)C and 1 / C: kernel arguments, i.e. SGPRs (there is no float SALU to derive them on)
@@ -46,6 +46,56 @@ struct Args {
     unsigned long long *dbg;   // profiling variant 64 only: where the s_memtime stamps go (fn2_debug_set_buffer)
     unsigned tab[MAX_TAB / 2];     // 16-bit entries (rg << 4 | py << 3 | u): the R_item real, then the P_item zero-only tasks of an item
 };
+typedef ArgsT<float> Args;
+
+// A task = (batch item n, y parity, row group rg of 4 lattice rows, B row block u).  "Real" tasks have B rows inside the
+// image; the others only write zeros.  Tasks are numbered item-major, separately for the two kinds; the (py, rg, u) of the
+// k-th task of a kind within an item comes from a table the launcher puts into the kernel arguments (all scalar work).
+struct Task { int n, py, rg, u, real; };
+
+template <class A> __device__ __forceinline__ Task decode_task(const A &p, bool real, int k)
+{
+    const unsigned per = real ? (unsigned)p.R_item : (unsigned)p.P_item;
+    const unsigned n = __umulhi((unsigned)k, real ? p.magic_r : p.magic_p);   // k / per (exact for k < 2^16, checked by the launcher)
+    const unsigned r = (unsigned)k - n * per;
+    // dword loads with a wave-uniform index: scalar loads from the kernel-argument segment
+    const unsigned i = __builtin_amdgcn_readfirstlane((real ? 0u : (unsigned)p.R_item) + r);
+    const unsigned e = (p.tab[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
+    Task t;
+    t.real = real ? 1 : 0;
+    t.n = __builtin_amdgcn_readfirstlane((int)n);
+    t.u = __builtin_amdgcn_readfirstlane((int)(e & 7u));
+    t.py = __builtin_amdgcn_readfirstlane((int)((e >> 3) & 1u));
+    t.rg = __builtin_amdgcn_readfirstlane((int)(e >> 4));
+    return t;
+}
+
+// host: the task table of one batch item (those whose B rows 4rg - 10 + 4u .. +3 meet [0, HL) first) and the division
+// constants; returns the number of tasks of the launch, or a negative FN2_E* code for shapes the table cannot describe
+template <class A> inline long build_task_table(A &a, int B, int H)
+{
+    const int HL = H / 2, NRG = (HL + 3) / 4;
+    if (2 * NRG * NU > MAX_TAB) return FN2_EUNSUPPORTED;
+    int R = 0, P = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int py = 0; py < 2; ++py)
+            for (int g = 0; g < NRG; ++g)
+                for (int u = 0; u < NU; ++u) {
+                    const int ib0 = 4 * g - DR + 4 * u;
+                    const bool real = ib0 + 3 >= 0 && ib0 < HL;
+                    if (real != (pass == 0)) continue;
+                    const unsigned e = (unsigned)((g << 4) | (py << 3) | u), i = (unsigned)(R + P);
+                    a.tab[i >> 1] = (i & 1u) ? (a.tab[i >> 1] | (e << 16)) : e;
+                    if (real) ++R; else ++P;
+                }
+    a.R_item = R; a.P_item = P;
+    a.magic_r = R ? (unsigned)((0x100000000ull + R - 1) / R) : 0u;
+    a.magic_p = P ? (unsigned)((0x100000000ull + P - 1) / P) : 0u;
+    if ((long)B * (R > P ? R : P) >= 65536) return FN2_EUNSUPPORTED;   // the magic-number division is exact below 2^16
+    const long ntasks = (long)B * (R + P);
+    if (ntasks > 0x3fffffffL) return FN2_EINVAL;
+    return ntasks;
+}
 
 // wave roles: A column blocks of role r, and the B column blocks they meet
 constexpr int NAB = 2;                            // A blocks per wave

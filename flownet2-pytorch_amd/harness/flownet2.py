@@ -7,8 +7,9 @@ concat groups (models.py:133-138, :145-150, :157-161, :170-174) use ``Resample2d
 first two, which build the 12-channel input of the next sub-network, are the fused one-pass kernel ``WarpDiffNormCat``
 (SURVEY.md 8f N2), and FlowNetC's cost volume carries its LeakyReLU + concat epilogue (N1).
 
-``half()``: the convolution stacks run in fp16, the three custom layers keep fp32 operands (the reference wraps them in
-tofp32 / tofp16 the same way, models.py:44-49).
+``half()``: the convolution stacks run in fp16; Resample2d / ChannelNorm keep fp32 operands (the reference wraps the custom layers
+in tofp32 / tofp16, models.py:44-49; its resample kernels are float-only), the cost volume of the no-grad path takes the half
+features directly (one f16 MFMA per block product, fused LeakyReLU + concat, half output).
 """
 import torch
 from torch import nn
@@ -158,7 +159,10 @@ class FlowNetCCore(_Refiner):                        # networks/FlowNetC.py:13-1
         redir = self.conv_redir(c3a)
         dt = c3a.dtype
         if not torch.is_grad_enabled():
-            merged = self.corr_fused(c3a.float(), c3b.float(), redir.float()).to(dt)
+            if dt == torch.float16:      # half tensors are matrix operands as they are (csrc/correlation_f16_fwd.hip): no casts
+                merged = self.corr_fused(c3a.contiguous(), c3b.contiguous(), redir)
+            else:
+                merged = self.corr_fused(c3a.float(), c3b.float(), redir.float()).to(dt)
         else:
             merged = torch.cat((redir, self.corr_activation(self.corr(c3a.float(), c3b.float()).to(dt))), 1)
         c3_1 = self.conv3_1(merged)
