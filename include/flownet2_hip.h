@@ -74,6 +74,9 @@ enum {
                                 Needs f32, k = 1, s1 = 1, s2 = 2, pad == md == 20, even H, W % 8 == 0, W <= 64,
                                 C % 64 == 0, 16 B aligned tensors (forward also out_batch_stride % 4 == 0); the forward
                                 launcher additionally declines H > 512 and B x tasks-per-item >= 65536.
+                                Half tensors (dtype FN2_F16) with this selector or AUTO, forward only, C % 128 == 0: the same
+                                tiling with ONE f16 product per block (the operands are f16 as they are; exact fp32 products and
+                                sums, result rounded to half: csrc/correlation_f16_fwd.hip).
                                 What FN2_CORR_AUTO picks, forward and backward, for FlowNetC's cost volume; shapes the
                                 launcher declines go on to FN2_CORR_MFMA_F32 / FN2_CORR_DIRECT under AUTO. */
 };
