@@ -481,6 +481,26 @@ def main():
         except Exception as exc:   # debug library not built: keep torch's number and say so
             copy_kernel += f" (fn2_debug_stream_copy unavailable: {exc!r})"
         del src, dst
+        # what this box sustains on the matrix pipe (register-only f16 MFMA stream on every SIMD): the boxes of the pool differ by
+        # up to 20 % on the whole step; with the copy ceiling this tells a slow clock from slow memory
+        mfma_tflops = None
+        try:
+            import ctypes
+            import fn2_capi
+            dl = fn2_capi.debug_lib()
+            sink = torch.zeros(1024, device=dev)
+            flop = ctypes.c_double(0.0)
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            run = lambda: fn2_capi.check(dl.fn2_debug_mfma_probe(ctypes.c_void_p(sink.data_ptr()), 4000, 512, ctypes.byref(flop), st),
+                                         "fn2_debug_mfma_probe")
+            run()
+            pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            for s_, e_ in pev:
+                s_.record(); run(); e_.record()
+            torch.cuda.synchronize()
+            mfma_tflops = round(flop.value / (min(s_.elapsed_time(e_) for s_, e_ in pev) * 1e-3) / 1e12, 1)
+        except Exception:
+            mfma_tflops = None
         line = {
             "metric": "image-pairs/sec, FlowNet2 custom-layer hot path (Correlation + Resample2d + ChannelNorm) fwd+bwd @ 384x512 "
                       "bs8 -- the whole FlowNet2C network's fwd+bwd image-pairs/sec is flownet2c.fwd_bwd_image_pairs_per_s; "
@@ -540,6 +560,10 @@ def main():
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
             "per_rank": per_rank,
+            "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1),
+                    "note": "register-only f16 MFMA stream (dense peak 2500) and streaming copy on THIS box.  The pool's boxes differ by up "
+                            "to 20 % on the step (0.205-0.21 vs 0.245-0.26 ms) while these two probes agree within 3 % across them "
+                            "(DESIGN.md 5): neither the matrix clock nor the streaming bandwidth explains the slow boxes"},
         }
         assert len(per_rank) == world and all(r["finite"] for r in per_rank), per_rank
         if share:

@@ -251,6 +251,39 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(scf4 *__restrict__ dst
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
+// Clock probe (bench.py's `box.mfma_probe_TFLOPs`): every SIMD of the chip runs a register-only stream of independent
+// v_mfma_f32_16x16x32_f16 from 4 waves -- no memory, no LDS -- so the achieved rate is (matrix-pipe rate) x (the shader clock this
+// box sustains under load): the boxes of the pool differ by 20 % on the whole step, this number says whether it is the clock.
+__global__ __launch_bounds__(1024) void mfma_probe_kernel(float *sink, int iters)
+{
+    typedef float pf4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 ph8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    pf4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (pf4){0.0f, 0.0f, 0.0f, 0.0f};
+    ph8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * (lane - i)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+// launches the probe; returns the number of MFMA FLOP it executes in *flop (0 on error)
+extern "C" int fn2_debug_mfma_probe(void *sink, int iters, int workgroups, double *flop, void *stream)
+{
+    if (!sink || iters < 1 || workgroups < 1 || !flop) return FN2_EINVAL;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)workgroups), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       static_cast<float *>(sink), iters);
+    *flop = (double)workgroups * 16.0 * iters * 8.0 * 16384.0;   // 16 waves x iters x 8 MFMAs x 2 * 16 * 16 * 32 FLOP
+    return fn2::launch_status();
+}
+
 extern "C" int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, int nontemporal, void *stream)
 {
     if (!dst || !src || (bytes % 16) || !fn2::aligned(dst, 16) || !fn2::aligned(src, 16) || blocks < 1) return FN2_EINVAL;

@@ -31,6 +31,9 @@ void fn2_debug_set_buffer(void *device_ptr);
 /* float4 grid-stride device-to-device copy of `bytes` (multiple of 16) with `blocks` workgroups of 256 lanes: the streaming
  * ceiling bench.py reports next to the 8 TB/s spec peak */
 int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, int nontemporal, void *stream);
+/* register-only f16 MFMA stream on every SIMD (`workgroups` x 16 waves x iters x 8 MFMAs): a probe of the shader clock the box
+ * sustains; *flop receives the FLOP count, `sink` is a device buffer of >= 4 KB that is never written */
+int fn2_debug_mfma_probe(void *sink, int iters, int workgroups, double *flop, void *stream);
 #ifdef __cplusplus
 }
 #endif
