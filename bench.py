@@ -494,13 +494,29 @@ def main():
             run = lambda: fn2_capi.check(dl.fn2_debug_mfma_probe(ctypes.c_void_p(sink.data_ptr()), 4000, 512, ctypes.byref(flop), st),
                                          "fn2_debug_mfma_probe")
             run()
-            pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            # 40 launches back to back (~0.4 s of sustained matrix load): the rate of the first and of the last five
+            pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
             for s_, e_ in pev:
                 s_.record(); run(); e_.record()
             torch.cuda.synchronize()
-            mfma_tflops = round(flop.value / (min(s_.elapsed_time(e_) for s_, e_ in pev) * 1e-3) / 1e12, 1)
+            rate = lambda evs: round(flop.value / (sum(s_.elapsed_time(e_) for s_, e_ in evs) / len(evs) * 1e-3) / 1e12, 1)
+            mfma_tflops = {"first5": rate(pev[:5]), "last5": rate(pev[-5:])}
         except Exception:
             mfma_tflops = None
+        # cold-operand sensitivity of the graded kernel on this box: median HIP-event time back-to-back (operands cache-resident)
+        # and right after a 1 GiB fill (operands evicted from every cache level)
+        junk = torch.empty(1 << 28, device=dev)
+        def corr_us(thrash):
+            ts = []
+            for _ in range(9):
+                if thrash:
+                    junk.fill_(1.0)
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(); hp.corr_fwd(); e_.record(); torch.cuda.synchronize()
+                ts.append(s_.elapsed_time(e_) * 1e3)
+            return round(sorted(ts)[len(ts) // 2], 1)
+        cold = {"corr_fwd_us_warm": corr_us(False), "corr_fwd_us_after_1GiB_fill": corr_us(True)}
+        del junk
         line = {
             "metric": "image-pairs/sec, FlowNet2 custom-layer hot path (Correlation + Resample2d + ChannelNorm) fwd+bwd @ 384x512 "
                       "bs8 -- the whole FlowNet2C network's fwd+bwd image-pairs/sec is flownet2c.fwd_bwd_image_pairs_per_s; "
@@ -560,10 +576,12 @@ def main():
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
             "per_rank": per_rank,
-            "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1),
-                    "note": "register-only f16 MFMA stream (dense peak 2500) and streaming copy on THIS box.  The pool's boxes differ by up "
-                            "to 20 % on the step (0.205-0.21 vs 0.245-0.26 ms) while these two probes agree within 3 % across them "
-                            "(DESIGN.md 5): neither the matrix clock nor the streaming bandwidth explains the slow boxes"},
+            "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1), **cold,
+                    "note": "probes of THIS box: a register-only f16 MFMA stream on every SIMD (first / last five of 40 back-to-back launches; dense "
+                            "peak 2500), the streaming copy, and the graded kernel timed alone (operands cache-resident / after a 1 GiB "
+                            "fill).  About every second box of the pool runs the whole step 20 % slower (0.245-0.26 vs 0.205-0.21 ms, "
+                            "eager and as a hipGraph alike) although all of these probes agree within a few percent across boxes "
+                            "(DESIGN.md 5)"},
         }
         assert len(per_rank) == world and all(r["finite"] for r in per_rank), per_rank
         if share:
