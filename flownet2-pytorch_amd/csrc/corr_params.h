@@ -23,6 +23,8 @@ int corr_forward_mfma_f32(const float *in1, const float *in2, float *out, long o
 bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_bs, float slope, int B, int C, int H, int W,
                        int variant, hipStream_t s);
+int corr_forward_f16x2_wide(const float *in1, const float *in2, float *out, long out_bs, float slope, int B, int C, int H, int W,
+                            hipStream_t s);   // W > 64 (correlation_f16x2_wide.hip)
 
 // half tensors (correlation_f16_fwd.hip): one f16 MFMA per block product, no split
 bool corr_f16_fwd_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);

@@ -515,7 +515,7 @@ bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int m
 {
     if (dtype != FN2_F32) return false;
     if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md / 2 != hf::DR || (md & 1)) return false;
-    if (C % (2 * hf::CK) != 0 || C < 2 * hf::CK || (H & 1) || (W % 8) != 0 || W > 64) return false;
+    if (C % (2 * hf::CK) != 0 || C < 2 * hf::CK || (H & 1) || (W % 8) != 0) return false;   // W > 64: correlation_f16x2_wide.hip
     if ((long)C * H * W * 4 >= 0x7fffffffL) return false;   // 32-bit buffer offsets per batch item
     return true;
 }
@@ -525,6 +525,7 @@ int corr_forward_f16x2(const float *in1, const float *in2, float *out, long out_
                        int variant, hipStream_t s)
 {
     if (!aligned(in1, 16) || !aligned(in2, 16) || !aligned(out, 16) || (out_bs % 4) != 0) return FN2_EALIGN;
+    if (W > 64) return variant == 0 ? corr_forward_f16x2_wide(in1, in2, out, out_bs, slope, B, C, H, W, s) : FN2_EINVAL;
     hf::Args a;
     a.in1 = in1; a.in2 = in2; a.out = out; a.out_bs = out_bs; a.slope = slope;
     a.fC = (float)C; a.rC = 1.0f / (float)C;

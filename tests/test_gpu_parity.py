@@ -542,6 +542,54 @@ def test_correlation_f16x2_vs_oracle(dev, oracle, case):
     assert float((direct - out).abs().max()) <= 2e-6
 
 
+F16X2_WIDE_CASES = [   # (B, C, H, W), W > 64: column windows of 32 pixels (csrc/correlation_f16x2_wide.hip)
+    (1, 64, 8, 72), (2, 64, 10, 96), (1, 128, 20, 128), (1, 64, 6, 200), (3, 64, 14, 104), (1, 256, 56, 128), (1, 64, 2, 136),
+]
+
+
+@pytest.mark.parametrize("case", F16X2_WIDE_CASES)
+def test_correlation_f16x2_wide_vs_oracle(dev, oracle, case):
+    """Maps wider than 64 pixels (Sintel-size inputs: conv3 is 56 x 128) on the windowed f16x2 forward kernel: every output
+    written, fp32-rounding close to the oracle, selected by FN2_CORR_AUTO, same fused epilogue, same block scaling (tiny
+    operands) and the same fp32 recomputation of outputs whose operands do not fit an f16."""
+    import fn2_capi
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    ad, bd = to_dev(a, dev), to_dev(b, dev)
+    out = torch.full((B, 441, H, W), float("nan"), device=dev)
+    fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2, out=out)
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all(), "wide f16x2 kernel left output elements unwritten"
+    direct = fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    assert float((direct - out).abs().max()) <= 2e-6
+    for n in ((0, B - 1) if B > 1 else (0,)):
+        ref = oracle.corr_fwd(a[n:n + 1], b[n:n + 1], 20, 1, 20, 1, 2)
+        assert max_abs(o[n:n + 1], ref) <= 2e-6, "two-term f16 split should agree with the fp32 oracle to rounding"
+    auto = torch.full_like(out, float("nan"))
+    fn2_capi.correlation_forward(ad, bd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_AUTO, out=auto)
+    assert torch.equal(auto, out), "FN2_CORR_AUTO should select the f16x2 kernel for this configuration"
+    # fused LeakyReLU + channel slice
+    buf = torch.full((B, 8 + 441 + 3, H, W), 7.0, device=dev)
+    fn2_capi.correlation_forward_fused(ad, bd, buf, 8, 0.1, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_AUTO)
+    assert (buf[:, :8] == 7.0).all() and (buf[:, 8 + 441:] == 7.0).all()
+    assert torch.equal(buf[:, 8:8 + 441], torch.nn.functional.leaky_relu(out, 0.1))
+    # tiny operands: the block scale keeps fp32-class relative accuracy
+    sa, sb = 2.0 ** -21, 2.0 ** -19
+    tiny = fn2_capi.correlation_forward(ad * sa, bd * sb, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    assert float((tiny / (sa * sb) - out).abs().max()) <= 4e-6
+    # operands beyond the f16 range, inf and nan
+    a2, b2 = ad.clone(), bd.clone()
+    a2[0, 3, H // 2, W - 5] = 1.0e6; b2[0, 7, 1, 70] = -3.0e7; b2[B - 1, 9, H - 1, 3] = float("inf"); b2[B - 1, 1, 0, W // 2] = float("nan")
+    big = fn2_capi.correlation_forward(a2, b2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    ref = fn2_capi.correlation_forward(a2, b2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    assert torch.equal(torch.isfinite(big), torch.isfinite(ref)), "non-finite outputs must coincide"
+    fin = torch.isfinite(ref)
+    assert int((~fin).sum()) > 0
+    assert float(((big - ref)[fin].abs() / ref[fin].abs().clamp_min(1.0)).max()) <= 1e-5
+
+
 def test_correlation_f16x2_full_size_and_fused(dev, oracle):
     """BASELINE configs[1] shape: against the direct kernel everywhere and the oracle on two batch items; the fused
     LeakyReLU / channel-slice epilogue (fn2_correlation_forward_fused) is bit-identical to the unfused result."""
