@@ -35,6 +35,8 @@ void *corr_f16x2_get_debug_buffer();
 bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
                         int variant, hipStream_t s);
+int corr_backward_f16x2_wide(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
+                             hipStream_t s);   // W > 64 (correlation_f16x2_bwd_wide.hip)
 
 bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,

@@ -661,7 +661,7 @@ bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, i
 {
     if (dtype != FN2_F32) return false;
     if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md != 2 * hb::DR) return false;
-    if (C % hb::CG != 0 || C < hb::CG || (H & 1) || (W % 8) != 0 || W > 64) return false;
+    if (C % hb::CG != 0 || C < hb::CG || (H & 1) || (W % 8) != 0) return false;   // W > 64: correlation_f16x2_bwd_wide.hip
     if ((long)C * H * W * 4 >= 0x7fffffffL || (long)hb::D * hb::D * H * W * 4 >= 0x7fffffffL) return false;
     return true;
 }
@@ -671,6 +671,7 @@ int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, f
                         int variant, hipStream_t s)
 {
     if (!aligned(in1, 16) || !aligned(in2, 16) || !aligned(gout, 16) || !aligned(g1, 16) || !aligned(g2, 16)) return FN2_EALIGN;
+    if (W > 64) return variant == 0 ? corr_backward_f16x2_wide(in1, in2, gout, g1, g2, B, C, H, W, s) : FN2_EINVAL;
     hb::Args a;
     a.nbr[0] = in2; a.nbr[1] = in1; a.gout = gout; a.gin[0] = g1; a.gin[1] = g2;
     a.B = B; a.C = C; a.H = H; a.W = W;

@@ -391,6 +391,52 @@ def test_correlation_f16x2_backward_vs_oracle(dev, oracle, case):
     assert torch.equal(res[fn2_capi.FN2_CORR_AUTO][1], res[fn2_capi.FN2_CORR_MFMA_F16X2][1])
 
 
+BWD_F16X2_WIDE_CASES = [  # W > 64: centre windows of 64 pixels, two neighbour passes (csrc/correlation_f16x2_bwd_wide.hip)
+    (1, 64, 6, 72), (2, 64, 8, 96), (1, 64, 10, 104), (1, 128, 12, 128), (1, 64, 4, 200), (1, 64, 28, 136), (2, 64, 2, 80),
+]
+
+
+@pytest.mark.parametrize("case", BWD_F16X2_WIDE_CASES)
+def test_correlation_f16x2_backward_wide_vs_oracle(dev, oracle, case):
+    """Maps wider than 64 pixels on the windowed f16x2 backward kernel: every gradient element written, fp32-rounding close to
+    the oracle, selected by FN2_CORR_AUTO; tiny gradOutput (training magnitudes) keeps its relative accuracy; operands that do
+    not fit an f16 are recomputed in fp32."""
+    import fn2_capi
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C * 7 + H + W + 5)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    go = rng.standard_normal((B, 441, H, W)).astype(np.float32)
+    ad, bd, gd = to_dev(a, dev), to_dev(b, dev), to_dev(go, dev)
+    r1, r2 = oracle.corr_bwd(a, b, go, 20, 1, 20, 1, 2)
+    scale = max(1.0, float(np.abs(r1).max()))
+    res = {}
+    for algo in (fn2_capi.FN2_CORR_MFMA_F16X2, fn2_capi.FN2_CORR_AUTO):
+        g1 = torch.full((B, C, H, W), float("nan"), device=dev)
+        g2 = torch.full((B, C, H, W), float("nan"), device=dev)
+        fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=algo, out=(g1, g2))
+        n1, n2 = g1.cpu().numpy(), g2.cpu().numpy()
+        assert np.isfinite(n1).all() and np.isfinite(n2).all(), "unwritten gradient elements"
+        e1, e2 = max_abs(n1, r1), max_abs(n2, r2)
+        assert e1 <= 5e-6 * scale and e2 <= 5e-6 * scale, (algo, e1, e2)
+        res[algo] = (g1, g2)
+    assert torch.equal(res[fn2_capi.FN2_CORR_AUTO][0], res[fn2_capi.FN2_CORR_MFMA_F16X2][0]), "AUTO should select f16x2 here"
+    assert torch.equal(res[fn2_capi.FN2_CORR_AUTO][1], res[fn2_capi.FN2_CORR_MFMA_F16X2][1])
+    g1, g2 = res[fn2_capi.FN2_CORR_MFMA_F16X2]
+    sg = 2.0 ** -23
+    t1, t2 = fn2_capi.correlation_backward(ad, bd, gd * sg, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    assert float((t1 / sg - g1).abs().max()) <= 1e-5 * scale and float((t2 / sg - g2).abs().max()) <= 1e-5 * scale
+    a2, b2, g3 = ad.clone(), bd.clone(), gd.clone()
+    a2[0, 3, H // 2, W - 5] = 1.0e6; b2[0, 7, 1, 70] = -3.0e7; g3[0, 200, H - 1, 66] = 3.0e6; g3[B - 1, 220, 0, 3] = float("inf")
+    q1, q2 = fn2_capi.correlation_backward(a2, b2, g3, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    f1, f2 = fn2_capi.correlation_backward(a2, b2, g3, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    for got, ref in ((q1, f1), (q2, f2)):
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(got), fin), "non-finite gradient elements must coincide"
+        assert int((~fin).sum()) > 0
+        assert float((got[fin].double() - ref[fin].double()).abs().max()) <= 2e-6 * float(ref[fin].abs().max())
+
+
 def test_correlation_f16x2_backward_out_of_range_operands(dev):
     """gradOutput / input values that do not fit an f16, infinities and NaNs: the affected gradient elements are
     recomputed in plain fp32 -- same finite/non-finite pattern as the general kernel, same values where finite."""
