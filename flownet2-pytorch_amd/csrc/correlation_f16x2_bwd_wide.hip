@@ -129,6 +129,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
     const int w8 = is_stage ? wave : wave - NSW;
     const int HL = p.H >> 1;
     const long HW = (long)p.H * p.W;
+    const int hw = p.H * p.W;
     const int per_fn = 2 * p.NRG * p.NXW * p.NCGR;          // tasks per (flip, batch item)
     const int ntasks = 2 * p.B * per_fn;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
@@ -211,10 +212,14 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
 
     if (is_stage) {
         // ================= staging waves =================
-        const int s_piece = (lane & 3) + 4 * ((lane >> 4) & 1);
-        const int s_row = (lane >> 2) & 3;
-        const int s_ch = 2 * w8 + (lane >> 5);
-        const int w_ofs = s_ch * CHS + (s_piece >> 1) * 64 + (s_piece & 1) * 16 + (s_row >> 1) * 32 + (s_row & 1) * 8;
+        // this lane's X chunk position: rebuilt from an opaque copy of the lane id wherever it is needed (kept in registers across
+        // the task loop it is spilled, and a scratch reload waits for vmcnt(0) -- for the X loads just requested)
+        auto x_ofs = [&]() {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int piece = (ln & 3) + 4 * ((ln >> 4) & 1), row = (ln >> 2) & 3, chn = 2 * w8 + (ln >> 5);
+            return chn * CHS + (piece >> 1) * 64 + (piece & 1) * 16 + (row >> 1) * 32 + (row & 1) * 8;
+        };
         const unsigned xbytes = (unsigned)(p.C * HW * 4), gbytes = (unsigned)(D * D * HW * 4);
 
         // G image of step v = (pass, u): staging wave w copies centre row ai = w, one DMA instruction per displacement column
@@ -241,10 +246,13 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         auto x_issue = [&](XSet &L, const Task &tk, int v, int ch) {
             const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
             const int u = v >= NU ? v - NU : v;
-            const int il = 4 * tk.rg - DR + 4 * u + s_row;
-            const int x = nbr_x0(tk, v) + 8 * s_piece;
+            int ln = lane;   // the lane geometry is rebuilt here (opaque copy): four registers less across the task loop
+            asm volatile("" : "+v"(ln));
+            const int piece = (ln & 3) + 4 * ((ln >> 4) & 1), row = (ln >> 2) & 3, chn = 2 * w8 + (ln >> 5);
+            const int il = 4 * tk.rg - DR + 4 * u + row;
+            const int x = nbr_x0(tk, v) + 8 * piece;
             const bool ok = il >= 0 && il < HL && x >= 0 && x < p.W;
-            const unsigned vo = ok ? (unsigned)((s_ch * HW + (long)(2 * il + tk.py) * p.W + x) * 4) : 0x80000000u;
+            const unsigned vo = ok ? (unsigned)((chn * hw + (2 * il + tk.py) * p.W + x) * 4) : 0x80000000u;   // < 2^31 (applicable())
 #pragma unroll
             for (int k = 0; k < XK; ++k) {
                 const int soff = (int)((tk.cg * CG + ch * CK + 2 * NSW * k) * HW * 4);
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
             }
         };
         f16s::scale2_t sc_x = f16s::scale2_from_exp(0);
-        auto x_write1 = [&](const XSet &L, char *buf, int k) {
+        auto x_write1 = [&](const XSet &L, char *buf, int w_ofs, int k) {
             const f4 x0 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][0]), sc_x), x1 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][1]), sc_x);
             char *dst = buf + w_ofs + k * 2 * NSW * CHS;
 #pragma unroll
@@ -318,10 +326,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
                 // phase 1 (the matrix waves gather the G operands of v): request the next X chunks, write both X chunks of v
                 if (v + 1 < tk.nv) { x_issue(N0, tk, v + 1, 0); x_issue(N1, tk, v + 1, 1); }
                 else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
+                const int w_ofs = x_ofs();
 #pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k);
+                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, w_ofs, k);
 #pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, k);
+                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, w_ofs, k);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 // phase 2 (all MFMAs of v): the next G image by DMA (and the next task's operand sample, ahead of it)
                 if (v + 1 < tk.nv) g_dma(tk, v + 1);

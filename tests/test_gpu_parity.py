@@ -1251,7 +1251,8 @@ def test_correlation_auto_falls_back_when_f16x2_declines(dev):
 
 
 # ------------------------------------------------------------------ half tensors on the matrix cores (correlation_f16_fwd.hip)
-@pytest.mark.parametrize("case", [(1, 128, 6, 8), (2, 128, 16, 24), (1, 256, 22, 56), (1, 128, 46, 64), (3, 128, 2, 16), (2, 256, 48, 64)])
+@pytest.mark.parametrize("case", [(1, 128, 6, 8), (2, 128, 16, 24), (1, 256, 22, 56), (1, 128, 46, 64), (3, 128, 2, 16), (2, 256, 48, 64),
+                                  (1, 128, 8, 72), (2, 128, 10, 96), (1, 256, 56, 128), (1, 128, 4, 200), (3, 128, 6, 104)])   # W > 64: column windows
 def test_correlation_half_forward_matrix_kernel(dev, oracle, case):
     """Half inputs (the reference dispatches its kernels for at::Half, correlation_cuda_kernel.cu:386-415): the single-product f16
     MFMA kernel against the oracle on the half-rounded inputs.  Products are exact and accumulated in fp32 here (the reference
