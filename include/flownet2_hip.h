@@ -71,7 +71,9 @@ enum {
                                 scaled f16; the outputs they touch are recomputed by a plain fp32 fma chain (slow, exact
                                 semantics incl. inf / nan).  Operands far BELOW m (< 2^-27 m) lose relative accuracy:
                                 block scaling is not scale-invariant within a task, unlike the reference's fp32 products.
-                                Needs f32, k = 1, s1 = 1, s2 = 2, pad == md == 20, even H, W % 8 == 0, W <= 64,
+                                Needs f32, k = 1, s1 = 1, s2 = 2, pad == md == 20, even H, W % 8 == 0 (any width: maps
+                                wider than 64 pixels -- Sintel-size inputs -- run column-window variants of the same kernels,
+                                csrc/correlation_f16x2_wide.hip / _bwd_wide.hip, ~1.5-1.7x the time per pixel),
                                 C % 64 == 0, 16 B aligned tensors (forward also out_batch_stride % 4 == 0); the forward
                                 launcher additionally declines H > 512 and B x tasks-per-item >= 65536.
                                 Half tensors (dtype FN2_F16) with this selector or AUTO, forward only, C % 128 == 0: the same
