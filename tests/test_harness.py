@@ -177,6 +177,46 @@ def test_flownet2c_forward_paths_agree(dev):
 
 
 @pytest.mark.gpu
+def test_flownet2c_sintel_size_paths_agree(dev):
+    """A Sintel-size frame pair (1024 x 448: conv3 maps are 56 x 128, i.e. wider than the 64 pixels one tile row of the f16x2
+    kernels holds): the fused inference path, the separate modules and a plain-torch cost volume give the same flow, and the
+    Correlation module's gradients on features of that size are those of torch autograd."""
+    from harness.flownet2c import FlowNet2C
+    from harness.train import synthetic_batch
+    from networks.correlation_package.correlation import Correlation
+    torch.manual_seed(12)
+    net = FlowNet2C().to(dev).eval()
+    inputs, _ = synthetic_batch(1, 448, 1024, dev, seed=13)
+    with torch.no_grad():
+        fused = net(inputs)
+    assert tuple(fused.shape) == (1, 2, 448, 1024) and torch.isfinite(fused).all()
+    unfused = net(inputs).detach()
+    scale = float(fused.abs().max())
+    assert float((fused - unfused).abs().max()) <= 1e-5 * scale
+
+    class TorchCorr(torch.nn.Module):
+        def forward(self, a, b):
+            return _corr_torch(a, b)
+    hip_corr = net.corr
+    net.corr = TorchCorr()
+    try:
+        ref = net(inputs).detach()
+    finally:
+        net.corr = hip_corr
+    assert float((unfused - ref).abs().max()) <= 2e-4 * scale
+    g = torch.Generator().manual_seed(14)
+    a = torch.randn(1, 64, 56, 128, generator=g).to(dev).requires_grad_()
+    b = torch.randn(1, 64, 56, 128, generator=g).to(dev).requires_grad_()
+    go = torch.randn(1, 441, 56, 128, generator=g).to(dev) * 1e-6            # training-size gradOutput
+    Correlation(20, 1, 20, 1, 2, 1)(a, b).backward(go)
+    g1, g2 = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    _corr_torch(a, b).backward(go)
+    for got, want in ((g1, a.grad), (g2, b.grad)):
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
 def test_flownet2c_train_steps(dev):
     from harness.train import Trainer, synthetic_batch
     tr = Trainer(dev, lr=1e-4, seed=2, bucket_bytes=16 << 20)
