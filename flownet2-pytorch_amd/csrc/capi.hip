@@ -159,6 +159,12 @@ static int corr_backward_impl(const void *in1, const void *in2, const void *grad
         return corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),
                                    static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, algo - 6000, s);
     }
+    // half tensors on FlowNetC's configuration: the single-product f16 kernel (correlation_f16_bwd.hip); AUTO or the f16x2 selector
+    if (!debug_variant && (algo == FN2_CORR_AUTO || algo == FN2_CORR_MFMA_F16X2) &&
+        corr_f16_bwd_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)) {
+        rc = corr_backward_f16(in1, in2, grad_out, grad_in1, grad_in2, B, C, H, W, s);
+        if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
+    }
     if (!debug_variant && algo == FN2_CORR_MFMA_F16X2 && !f16x2_ok) return FN2_EUNSUPPORTED;
     if (!debug_variant && (algo == FN2_CORR_MFMA_F16X2 || (algo == FN2_CORR_AUTO && f16x2_ok))) {
         rc = corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),

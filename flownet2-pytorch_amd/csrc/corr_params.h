@@ -30,6 +30,10 @@ int corr_forward_f16x2_wide(const float *in1, const float *in2, float *out, long
 bool corr_f16_fwd_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_forward_f16(const void *in1, const void *in2, void *out, long out_bs, float slope, int B, int C, int H, int W, hipStream_t s);
 
+// half tensors, backward (correlation_f16_bwd.hip): one f16 MFMA per product, fp32 sums
+bool corr_f16_bwd_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
+int corr_backward_f16(const void *in1, const void *in2, const void *gout, void *g1, void *g2, int B, int C, int H, int W, hipStream_t s);
+
 void corr_f16x2_set_debug_buffer(void *p);
 void *corr_f16x2_get_debug_buffer();
 bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);

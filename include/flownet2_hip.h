@@ -76,9 +76,10 @@ enum {
                                 csrc/correlation_f16x2_wide.hip / _bwd_wide.hip, ~1.5-1.7x the time per pixel),
                                 C % 64 == 0, 16 B aligned tensors (forward also out_batch_stride % 4 == 0); the forward
                                 launcher additionally declines H > 512 and B x tasks-per-item >= 65536.
-                                Half tensors (dtype FN2_F16) with this selector or AUTO, forward only, C % 128 == 0: the same
-                                tiling with ONE f16 product per block (the operands are f16 as they are; exact fp32 products and
-                                sums, result rounded to half: csrc/correlation_f16_fwd.hip).
+                                Half tensors (dtype FN2_F16) with this selector or AUTO: the same tilings with ONE f16 product
+                                per block (the operands are f16 as they are; exact fp32 products, fp32 sums, result rounded to
+                                half): forward C % 128 == 0, any width (csrc/correlation_f16_fwd.hip); backward C % 64 == 0,
+                                W <= 64 (csrc/correlation_f16_bwd.hip; wider maps: the general kernel).
                                 What FN2_CORR_AUTO picks, forward and backward, for FlowNetC's cost volume; shapes the
                                 launcher declines go on to FN2_CORR_MFMA_F32 / FN2_CORR_DIRECT under AUTO. */
 };

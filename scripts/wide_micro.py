@@ -34,4 +34,8 @@ for (B, C, H, W) in ((1, 256, 56, 128), (8, 256, 56, 128), (4, 256, 48, 64), (8,
     ah, bh = a.half(), b.half(); oh = torch.empty(B, 441, H, W, device=dev, dtype=torch.float16)
     line += "  fwd half %.1f us" % timeit(lambda: fn2_capi.correlation_forward(ah, bh, 20, 1, 20, 1, 2, out=oh))
     line += " (general kernel %.1f us)" % timeit(lambda: fn2_capi.correlation_forward(ah, bh, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT, out=oh), n=5)
+    if W <= 64:
+        gh = go.half(); h1 = torch.empty_like(ah); h2 = torch.empty_like(ah)
+        line += "  bwd half %.1f us" % timeit(lambda: fn2_capi.correlation_backward(ah, bh, gh, 20, 1, 20, 1, 2, out=(h1, h2)))
+        line += " (general kernel %.1f us)" % timeit(lambda: fn2_capi.correlation_backward(ah, bh, gh, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT, out=(h1, h2)), n=3)
     print(line)

@@ -1283,9 +1283,52 @@ def test_correlation_half_forward_matrix_kernel(dev, oracle, case):
     assert float((buf[:, 8:8 + 441].float() - want).abs().max()) <= 2.0 ** -11 * scale + 1e-6
 
 
+@pytest.mark.parametrize("case", [(1, 64, 6, 8), (2, 64, 16, 24), (1, 128, 22, 56), (1, 64, 46, 64), (3, 64, 2, 16), (2, 256, 48, 64), (1, 192, 12, 40)])
+def test_correlation_half_backward_matrix_kernel(dev, oracle, case):
+    """Half tensors through the backward (the reference dispatches it for at::Half, correlation_cuda_kernel.cu:460-554, and sums in
+    half there; here the products are exact and the sums fp32, like the oracle on the half-rounded inputs): the single-product
+    f16 MFMA kernel against the oracle -- the only error left is the rounding of each result to half; every element written; AUTO
+    and the explicit selector reach it; non-finite inputs give the general kernel's finite / non-finite pattern."""
+    import fn2_capi
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C + H + W + 9)
+    a = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).half()
+    b = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).half()
+    go = torch.from_numpy(rng.standard_normal((B, 441, H, W)).astype(np.float32)).half()
+    ad, bd, gd = a.to(dev), b.to(dev), go.to(dev)
+    r1, r2 = oracle.corr_bwd(a.float().numpy(), b.float().numpy(), go.float().numpy(), 20, 1, 20, 1, 2)
+    g1 = torch.full((B, C, H, W), float("nan"), dtype=torch.float16, device=dev)
+    g2 = torch.full((B, C, H, W), float("nan"), dtype=torch.float16, device=dev)
+    fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, out=(g1, g2))               # AUTO
+    for got, ref in ((g1, r1), (g2, r2)):
+        n = got.float().cpu().numpy()
+        assert np.isfinite(n).all(), "unwritten gradient elements"
+        assert (np.abs(n - ref) <= 2.0 ** -11 * np.abs(ref) + 2e-6 * np.abs(ref).max() + 1e-7).all(), float(np.abs(n - ref).max())
+    s1, s2 = fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+    assert torch.equal(s1, g1) and torch.equal(s2, g2)                                     # the explicit selector: same kernel
+    d1, d2 = fn2_capi.correlation_backward(ad, bd, gd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+    scale = max(1.0, float(np.abs(r1).max()))
+    assert float((d1.float() - g1.float()).abs().max()) <= 3e-3 * scale and float((d2.float() - g2.float()).abs().max()) <= 3e-3 * scale
+    # tiny gradOutput (f16 subnormals included) and non-finite values
+    t1, t2 = fn2_capi.correlation_backward(ad, bd, gd * 2.0 ** -12, 20, 1, 20, 1, 2)
+    q1, q2 = oracle.corr_bwd(a.float().numpy(), b.float().numpy(), (go * 2.0 ** -12).float().numpy(), 20, 1, 20, 1, 2)
+    for got, ref in ((t1, q1), (t2, q2)):
+        assert (np.abs(got.float().cpu().numpy() - ref) <= 2.0 ** -11 * np.abs(ref) + 6e-8 + 2e-6 * np.abs(ref).max()).all()
+    if H >= 6 and W >= 16:
+        a2, b2, g3 = ad.clone(), bd.clone(), gd.clone()
+        a2[0, 3, H // 2, W - 5] = float("inf"); b2[0, 7, 1, 3] = float("nan"); g3[B - 1, 220, 0, 3] = float("inf"); g3[0, 17, H - 1, 9] = 65504.0
+        n1, n2 = fn2_capi.correlation_backward(a2, b2, g3, 20, 1, 20, 1, 2)
+        f1, f2 = fn2_capi.correlation_backward(a2.float(), b2.float(), g3.float(), 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+        for got, ref in ((n1, f1), (n2, f2)):
+            small = torch.isfinite(ref) & (ref.abs() < 6.0e4)       # representable in half
+            assert torch.equal(torch.isnan(got), torch.isnan(ref)), "nan pattern"
+            assert bool(torch.isfinite(got)[small].all()) and int((~torch.isfinite(ref)).sum()) > 0
+            assert float((got.float() - ref)[small].abs().max()) <= 2.0 ** -10 * float(ref[small].abs().max())
+
+
 def test_correlation_half_special_values_and_wrapper(dev):
     """inf / nan / f16-subnormal inputs are matrix operands like any other (no out-of-range path to get wrong), and the
-    Correlation module takes half tensors end to end (the backward for half stays on the general kernel)."""
+    Correlation module takes half tensors end to end (forward and backward on the half matrix-core kernels)."""
     import fn2_capi
     from networks.correlation_package.correlation import Correlation
     g = torch.Generator().manual_seed(51)
