@@ -12,7 +12,7 @@
 //     the fp32 kernel's LDS image without its second term;
 //   - G operand (gradOutput): the image [ai][ti][bi][x] stays fp32 -- the gather layout of the fp32 kernel (conflict-free strides,
 //     one address register + immediates) is kept as it is -- so it cannot be copied by LDS-DMA: the staging waves load the half
-//     rows (requested a whole step ahead, 11 loads of 16 B per lane and u), convert (v_cvt_f32_f16) and write them while the
+//     rows (requested a whole step ahead, 12 loads of 16 B per lane and u), convert (v_cvt_f32_f16) and write them while the
 //     matrix waves run the MFMAs; the matrix waves gather fp32 values and pack pairs with v_cvt_pk_f16_f32 (exact: the values
 //     were halfs);
 //   - the epilogue scales by 1/C, rounds to half (round to nearest even, as T(sum / nelems)) and stores 8 bytes per lane.
@@ -25,8 +25,13 @@
 
 #include "corr_params.h"
 
+#ifndef FN2_HBH_ABL   // timing ablations (scripts/half_bwd_abl.sh): 1 no MFMA, 2 no gather, 4 no G conversion / LDS writes,
+#define FN2_HBH_ABL 0 // 8 no X writes, 16 no global loads, 32 no epilogue; results are wrong unless 0
+#endif
+
 namespace fn2 {
 namespace hbh {
+constexpr int ABL = FN2_HBH_ABL;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -112,7 +117,7 @@ __device__ __forceinline__ float exact_grad(const Args &p, int flip, int n, int 
 
 constexpr int NSW = 4, NWAVES = NSW + 8;   // staging waves, waves per workgroup (3 per SIMD)
 constexpr int XK = 32 / (2 * NSW);          // X items (8 pixels of one channel row) per chunk and staging lane
-constexpr int NGL = (D + 1) / 2;            // G loads per lane and u: two displacement columns per instruction
+constexpr int NGL = 12;                     // G loads per lane and u: 4 neighbour rows x 3 blocks of 8 displacement columns
 struct XSet { u4 v[XK]; };
 struct GSet { u4 v[NGL]; };
 
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
     // ---- write-out of the epilogue image (all waves): 256 rows (channel, centre row) of 64 floats -> half rows of 128 B
     float *Es = reinterpret_cast<float *>(smem + X_OFS);
     auto store_rows = [&](const Task &tk) {
+        if (ABL & 32) return;
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int g = ln >> 4, xg = 4 * (ln & 15);
@@ -219,10 +225,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
             const unsigned vo = ok ? (unsigned)((s_ch * hw + (2 * il + tk.py) * p.W + 8 * s_piece) * 2) : 0x80000000u;
 #pragma unroll
             for (int k = 0; k < XK; ++k)
-                L.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, (int)((tk.cg * CG + ch * CK + 2 * NSW * k) * hw * 2), 0);
+                L.v[k] = (ABL & 16) ? (u4)(0x3c003c00u + lane) : __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, (int)((tk.cg * CG + ch * CK + 2 * NSW * k) * hw * 2), 0);
         };
         // 8 consecutive pixels (four dwords) -> the chunks (p0,p2,p4,p6) and (p1,p3,p5,p7) of the two parities
         auto x_write = [&](const XSet &L, char *buf) {
+            if (ABL & 8) { asm volatile("" ::"v"(L.v[0]), "v"(L.v[1]), "v"(L.v[2]), "v"(L.v[3])); return; }
 #pragma unroll
             for (int k = 0; k < XK; ++k) {
                 const u4 q = L.v[k];
@@ -231,46 +238,60 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
                 *(FN2_LDS(u2) *)(dst + PARS) = (u2){__builtin_amdgcn_perm(q[1], q[0], 0x07060302u), __builtin_amdgcn_perm(q[3], q[2], 0x07060302u)};
             }
         };
-        // G image of u: staging wave w holds centre row ai = w; load i of a lane: displacement column ti = 2 i + (lane >> 5),
-        // neighbour row bi = (lane >> 3) & 3, 8 pixels.  FLIP 0: tj = 4u + bi - ai, gO row = centre row ai; FLIP 1: tj = 20 - 4u - bi + ai,
-        // gO row = neighbour row bi.  Rows that do not exist get an out-of-range offset: the load returns zeros.
+        // G image of u: staging wave w holds centre row ai = w.  Load i = 3 bi + tb of a lane: neighbour row bi (a scalar of the
+        // instruction, like the displacement row tj and the gO row it implies), displacement column ti = 8 tb + (lane >> 3), 8 pixels
+        // (lane & 7).  FLIP 0: tj = 4u + bi - ai, gO row = centre row ai; FLIP 1: tj = 20 - 4u - bi + ai, gO row = neighbour row bi.
+        // Rows that do not exist get an out-of-range offset: the load returns zeros.  The lane mapping is chosen for the LDS writes of
+        // the converted rows: with (ti, 8-pixel piece) across the lanes the dword stores of gradInput2's image (column stride = 1 bank)
+        // hit 64 distinct banks; the first version (two ti, four bi, eight pieces per instruction) was 4- to 8-way conflicted there and
+        // the conversion took 33 of the kernel's 77 us (ablations: scripts/half_bwd_abl.sh).
         auto g_issue = [&](GSet &S, const Task &tk, int u, bool valid) {
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const int t2 = ln >> 5, bi = (ln >> 3) & 3, pc = ln & 7, ai = w8;
-            const int tj = tk.flip ? 20 - 4 * u - bi + ai : 4 * u + bi - ai;
-            const int il = tk.flip ? 4 * tk.rg - DR + 4 * u + bi : 4 * tk.rg + ai;
-            const bool ok = valid && tj >= 0 && tj < D && il >= 0 && il < HL && 8 * pc < p.W;
-            const unsigned vo = ok ? (unsigned)((((tj * D + t2) * p.H + 2 * il + tk.py) * p.W + 8 * pc) * 2) : 0x80000000u;
+            const int ts = ln >> 3, pc = ln & 7, ai = w8;
+            const unsigned vlo = (valid && 8 * pc < p.W) ? (unsigned)((ts * hw + 8 * pc) * 2) : 0x80000000u;
+            const unsigned vhi = ts + 16 < D ? vlo : 0x80000000u;                              // tb = 2: ti = 16 + ts < 21
 #pragma unroll
             for (int i = 0; i < NGL; ++i) {
-                const unsigned v = (2 * i + 1 < D || t2 == 0) ? vo : 0x80000000u;   // ti = 2 i + t2 < 21
-                S.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)v, 2 * i * hw * 2, 0);
+                const int bi = i / 3, tb = i % 3;
+                const int tj = tk.flip ? 20 - 4 * u - bi + ai : 4 * u + bi - ai;
+                const int il = tk.flip ? 4 * tk.rg - DR + 4 * u + bi : 4 * tk.rg + ai;
+                const bool ok = tj >= 0 && tj < D && il >= 0 && il < HL;                       // uniform
+                const int so = ok ? (((tj * D + 8 * tb) * p.H + 2 * il + tk.py) * p.W) * 2 : 0;
+                const unsigned v = ok ? (tb == 2 ? vhi : vlo) : 0x80000000u;
+                S.v[i] = (ABL & 16) ? (u4)(0x3c003c00u + lane) : __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)v, so, 0);
             }
         };
         auto g_write = [&](const GSet &S, const Task &tk) {
+            if (ABL & 4) {
+#pragma unroll
+                for (int i = 0; i < NGL; ++i) asm volatile("" ::"v"(S.v[i]));
+                return;
+            }
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const int t2 = ln >> 5, bi = (ln >> 3) & 3, pc = ln & 7;
-            const int lt = tk.flip ? GL<1>::TI : GL<0>::TI;
-            char *dst = smem + w8 * (tk.flip ? GL<1>::AI : GL<0>::AI) + t2 * lt + bi * 256 + pc * 32;
+            const int ts = ln >> 3, pc = ln & 7;
             if (tk.flip) {   // gradInput2's column stride is 4 bytes off a multiple of 16 (gather banks): dword stores
+                char *dst = smem + w8 * GL<1>::AI + ts * GL<1>::TI + pc * 32;
 #pragma unroll
                 for (int i = 0; i < NGL; ++i) {
-                    if (2 * i + 1 >= D && t2 != 0) continue;
+                    const int bi = i / 3, tb = i % 3;
+                    if (tb == 2 && ts + 16 >= D) continue;
                     const h8 h = __builtin_bit_cast(h8, S.v[i]);
-                    FN2_LDS(float) *d = (FN2_LDS(float) *)(dst + 2 * i * GL<1>::TI);
+                    FN2_LDS(float) *d = (FN2_LDS(float) *)(dst + 8 * tb * GL<1>::TI + bi * 256);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[e] = (float)h[e];
                 }
             } else {
+                char *dst = smem + w8 * GL<0>::AI + ts * GL<0>::TI + pc * 32;
 #pragma unroll
                 for (int i = 0; i < NGL; ++i) {
-                    if (2 * i + 1 >= D && t2 != 0) continue;
+                    const int bi = i / 3, tb = i % 3;
+                    if (tb == 2 && ts + 16 >= D) continue;
                     const h8 h = __builtin_bit_cast(h8, S.v[i]);
-                    *(FN2_LDS(f4) *)(dst + 2 * i * GL<0>::TI) = (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-                    *(FN2_LDS(f4) *)(dst + 2 * i * GL<0>::TI + 16) = (f4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+                    *(FN2_LDS(f4) *)(dst + 8 * tb * GL<0>::TI + bi * 256) = (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                    *(FN2_LDS(f4) *)(dst + 8 * tb * GL<0>::TI + bi * 256 + 16) = (f4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
                 }
             }
         };
@@ -370,7 +391,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
                             constexpr int sconst = FLIP ? bis * L::BI + (3 - bjs) * SB : bis * L::BI + bjs * L::TI;
                             const int ofs = fbase + sconst;
                             float v;
-                            if constexpr (FLIP) v = *reinterpret_cast<const float *>(smem + ofs);
+                            if (ABL & 2) v = 1.0f;
+                            else if constexpr (FLIP) v = *reinterpret_cast<const float *>(smem + ofs);
                             else v = *reinterpret_cast<const float *>(smem + ofs + 4 * XP);
                             if constexpr (check) {
                                 constexpr int hi = 10 - 4 * dj - bjs, lo = -10 - 4 * dj - bjs;   // lo <= vs <= hi
@@ -397,6 +419,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
                         x[ct] = *reinterpret_cast<const h8 *>(smem + X_OFS + (ct >> 1) * XBUF + xb + (ct & 1) * 16 * CHS + j * 64);
+                    if (ABL & 1) { asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])); return; }
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) {
                         if constexpr (f0 >= 0) acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[ct], gh[f0 >= 0 ? f0 : 0], acc[0][ct], 0, 0, 0);
@@ -449,11 +472,18 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
                 });
             });
         };
-        switch (role) {
-        case 0: scatter(std::integral_constant<int, 0>{}); break;
-        case 1: scatter(std::integral_constant<int, 1>{}); break;
-        case 2: scatter(std::integral_constant<int, 2>{}); break;
-        default: scatter(std::integral_constant<int, 3>{}); break;
+        if (ABL & 32) {
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) asm volatile("" ::"v"(acc[ab][ct]));
+        } else {
+            switch (role) {
+            case 0: scatter(std::integral_constant<int, 0>{}); break;
+            case 1: scatter(std::integral_constant<int, 1>{}); break;
+            case 2: scatter(std::integral_constant<int, 2>{}); break;
+            default: scatter(std::integral_constant<int, 3>{}); break;
+            }
         }
         __syncthreads();
         store_rows(tk);
