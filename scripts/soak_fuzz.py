@@ -22,6 +22,7 @@ while time.time() - t0 < budget:
         if rng.random() < 0.7: H += H & 1; W += (-W) % 4; C = max(16, C - C % 16)
         if rng.random() < 0.4:   # shapes the f16x2 matrix-core kernels take (FlowNetC's cost volume on maps up to 64 wide)
             md, C, H, W = 20, int(rng.choice([64, 128, 192, 256])), 2 * int(rng.integers(1, 31)), 8 * int(rng.integers(1, 9))
+            if rng.random() < 0.4: W, B = 8 * int(rng.integers(9, 33)), int(rng.integers(1, 3))   # wider than 64 px: column windows
         # operand magnitudes: the block-scaled f16x2 kernels must be fp32-class at any of them (errors below are RELATIVE to the
         # largest reference value); now and then a heavy-tailed operand (log-normal magnitudes) or a few huge outliers
         sc = lambda: np.float32(rng.choice([1e-7, 1e-3, 1.0, 1.0, 30.0, 1e4]))
@@ -42,6 +43,21 @@ while time.time() - t0 < budget:
         e = max(mx(g1.cpu().numpy(), r1) / max(1e-30, float(np.abs(r1).max())), mx(g2.cpu().numpy(), r2) / max(1e-30, float(np.abs(r2).max())))
         note("corr_bwd", e); assert e <= 6e-6, ("bwd", B, C, H, W, md, e)
         ncorr += 1
+        if md == 20 and C % 64 == 0 and H % 2 == 0 and W % 8 == 0 and rng.random() < 0.5:
+            # half tensors on the single-product kernels (forward C % 128 == 0; backward W <= 64; otherwise the general kernel):
+            # against the oracle on the half-rounded inputs, half an ulp of the result plus fp32 summation noise
+            ah, bh, gh = (torch.from_numpy(x / np.float32(max(1e-30, np.abs(x).max()))).half() for x in (a, b, go))   # unit range
+            rf = orc.corr_fwd(ah.float().numpy(), bh.float().numpy(), 20, 1, 20, 1, 2)
+            q1, q2 = orc.corr_bwd(ah.float().numpy(), bh.float().numpy(), gh.float().numpy(), 20, 1, 20, 1, 2)
+            oh = torch.full((B, 441, H, W), float("nan"), dtype=torch.float16, device=dev)
+            fn2_capi.correlation_forward(ah.to(dev), bh.to(dev), 20, 1, 20, 1, 2, out=oh)
+            h1 = torch.full((B, C, H, W), float("nan"), dtype=torch.float16, device=dev); h2 = torch.full_like(h1, float("nan"))
+            fn2_capi.correlation_backward(ah.to(dev), bh.to(dev), gh.to(dev), 20, 1, 20, 1, 2, out=(h1, h2))
+            for name, got, ref in (("half_fwd", oh, rf), ("half_bwd", h1, q1), ("half_bwd", h2, q2)):
+                gnp = got.float().cpu().numpy()
+                tol = 2.0 ** -11 * np.abs(ref) + 6.1e-5 + 4e-6 * np.abs(ref).max()     # half rounding (normal / subnormal) + summation order
+                bad = np.abs(gnp - ref) > tol
+                note(name, float(np.max(np.abs(gnp - ref) / tol))); assert not bad.any(), (name, B, C, H, W, float(np.abs(gnp - ref).max()))
     else:
         B, C, H, W, bil = int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 130)), int(rng.integers(1, 200)), bool(rng.integers(0, 2))
         ks = int(rng.choice([1, 1, 1, 2, 3]))   # window sums (kernel_size > 1) now and then
