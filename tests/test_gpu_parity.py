@@ -1234,7 +1234,7 @@ def test_correlation_auto_falls_back_when_f16x2_declines(dev):
     the fp32 MFMA / general kernels; the explicit selector reports FN2_EUNSUPPORTED."""
     import fn2_capi
     g = torch.Generator().manual_seed(41)
-    for shape in ((1, 64, 1024, 64), (10940, 64, 2, 8)):
+    for shape in ((1, 64, 1024, 64), (10940, 64, 2, 8), (1, 64, 1024, 72), (3700, 64, 2, 72)):   # the last two: column windows
         a = torch.randn(shape, generator=g).to(dev)
         b = torch.randn(shape, generator=g).to(dev)
         with pytest.raises(RuntimeError):
@@ -1248,6 +1248,15 @@ def test_correlation_auto_falls_back_when_f16x2_declines(dev):
             g1, g2 = fn2_capi.correlation_backward(a, b, go, 20, 1, 20, 1, 2)
             r1, r2 = fn2_capi.correlation_backward(a, b, go, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
             assert float((g1 - r1).abs().max()) <= 1e-5 and float((g2 - r2).abs().max()) <= 1e-5
+    # half tensors: the same launcher limits, the same fall-through (here to the general kernel)
+    for shape in ((1, 128, 1024, 16), (1, 128, 1024, 72)):
+        a = torch.randn(shape, generator=g).half().to(dev)
+        b = torch.randn(shape, generator=g).half().to(dev)
+        with pytest.raises(RuntimeError):
+            fn2_capi.correlation_forward(a, b, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F16X2)
+        out = fn2_capi.correlation_forward(a, b, 20, 1, 20, 1, 2)
+        ref = fn2_capi.correlation_forward(a, b, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT)
+        assert torch.equal(out, ref)
 
 
 # ------------------------------------------------------------------ half tensors on the matrix cores (correlation_f16_fwd.hip)
