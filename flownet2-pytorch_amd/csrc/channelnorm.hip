@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void chnorm_fwd_vec(const T *__restrict__ in, 
         V o;
 #pragma unroll
         for (int i = 0; i < N; ++i) o[i] = (T)__fsqrt_rn(acc[i]);
-        *reinterpret_cast<V *>(out + b * HW + p) = o;
+        store_out(reinterpret_cast<V *>(out + b * HW + p), o);
     }
 }
 
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void chnorm_bwd_vec(const T *__restrict__ in, 
             V r;
 #pragma unroll
             for (int i = 0; i < N; ++i) r[i] = (T)chnorm_grad((float)go[i], (float)x[i], (float)o[i]);
-            *reinterpret_cast<V *>(gin + off) = r;
+            store_out(reinterpret_cast<V *>(gin + off), r);
         }
     }
 }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16(Args p)
             if (lane_ok && (__builtin_amdgcn_classf(vals[i][0], 0x207) | __builtin_amdgcn_classf(vals[i][1], 0x207) |
                             __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
-            __builtin_amdgcn_raw_buffer_store_b64(finish(vals[i]), rso, (int)vo, (int)((tk.cg * CG + c) * hw * 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(finish(vals[i]), rso, (int)vo, (int)((tk.cg * CG + c) * hw * 2), 2);   // sc1: see correlation_f16x2_bwd.hip
         }
         if (bad) {   // non-finite sums: those outputs again, each over its own displacement window
 #pragma unroll 1

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16(ArgsH p)
                 for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * sl;
             }
             const u2 packed = {pk_f16(val[0], val[1]), pk_f16(val[2], val[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(packed, rso, (int)v, so0 + 4 * i * (int)(HW * 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(packed, rso, (int)v, so0 + 4 * i * (int)(HW * 2), 2);
         }
     };
 
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16_wide(ArgsHW p)
                 for (int e = 0; e < 4; ++e) val[e] = val[e] > 0.0f ? val[e] : val[e] * sl;
             }
             const u2 packed = {pk_f16(val[0], val[1]), pk_f16(val[2], val[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(packed, rso, (int)v, so0 + 8 * i * (int)(HW * 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(packed, rso, (int)v, so0 + 8 * i * (int)(HW * 2), 2);
         }
     };
 

@@ -170,7 +170,12 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2(Args p)
                                      __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
             if (!(VAR & 4))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, finish(vals[i], kx_mm)), rso, (int)v, so0 + 4 * i * (int)(HW * 4), (VAR & 1024) ? 0 : 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, finish(vals[i], kx_mm)), rso, (int)v, so0 + 4 * i * (int)(HW * 4),
+#ifdef FN2_ABL_FWDTEMPORAL   // timing ablation: temporal row stores
+                                                       0);
+#else
+                                                       (VAR & 1024) ? 0 : 2);
+#endif
         }
         // An operand did not fit an f16 (or is inf/nan): a second pass recomputes exactly those outputs in fp32 and stores the
         // row again (kept out of the loop above: inlined there, its live state pushes the row values into scratch).

@@ -61,6 +61,22 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define FN2_LDS(T) __attribute__((address_space(3))) T
 
+// Cache policy of the gradient row stores: sc1 (agent scope) -- written through the XCD's L2 as they are issued.  The eight L2s
+// are not coherent with each other, so everything a kernel wrote has to be in memory when it ends; left dirty (scope 0) the 50 MB
+// of gradients are flushed in one burst at the end of the kernel, which the NEXT kernel of the stream waits for: inside bench.py's
+// step sc1 measured 75.4 us against 77.0 for this kernel and 3 us less for the kernel after it (scripts/gpu_bench_ab.sh; the
+// forward kernel's rows have had it since round 2: temporal stores cost it 3 % of the step).  The same hint on the gO DMA (GNT)
+// costs 6 us: those rows ARE re-read, by the other channel groups and the other gradient.
+#ifdef FN2_ABL_BWDTEMPORAL   // timing ablation
+constexpr int BWD_STORE_AUX = 0;
+#else
+constexpr int BWD_STORE_AUX = 2;
+#endif
+#ifdef FN2_ABL_GNT
+constexpr int G_LOAD_AUX = 2;
+#else
+constexpr int G_LOAD_AUX = 0;
+#endif
 constexpr int DR = 10, D = 21, NU = 6;
 constexpr int CG = 64, NCT = CG / 16;             // channels per task, channel tiles of 16
 constexpr int CK = 32;                            // channels per X chunk (2 tiles)
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                  __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
             if (!(VAR & 4))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), BWD_STORE_AUX);
         }
         // Non-finite values (an operand beyond the f16 range): a second pass recomputes exactly those outputs with an fp32 fma
         // chain and stores the row again.  Kept out of the loop above: inlined there, its live state pushes the row values
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                 const int l0 = tk.flip ? ai * GL<1>::AI : ai * GL<0>::AI, lt = tk.flip ? GL<1>::TI : GL<0>::TI;
 #pragma unroll
                 for (int ti = 0; ti < D; ++ti)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (FN2_LDS(void) *)(smem + l0 + ti * lt), 16, (int)vo, ti * (int)(HW * 4), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (FN2_LDS(void) *)(smem + l0 + ti * lt), 16, (int)vo, ti * (int)(HW * 4), 0, G_LOAD_AUX);
             }
         };
         // X chunk (u, ch): neighbour rows 4rg - 10 + 4u .. +3, channels cg*64 + 32*ch .. +31; item k of a lane: channel 2 NSW k + s_ch

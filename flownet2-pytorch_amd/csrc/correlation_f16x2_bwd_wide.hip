@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
             if (lane_ok && (__builtin_amdgcn_classf(vals[i][0], 0x207) | __builtin_amdgcn_classf(vals[i][1], 0x207) |
                             __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 2);   // sc1: see correlation_f16x2_bwd.hip
         }
         if (bad) {   // an operand beyond the f16 range: those outputs again, as fp32 fma chains
 #pragma unroll 1

@@ -29,6 +29,28 @@ static inline size_t dtype_size(int dtype)
     }
 }
 
+// Store of a finished output element / vector (written once, read by a LATER kernel): agent scope (sc1) -- written through the
+// XCD's L2 as it is issued.  The eight L2s are not coherent with each other, so everything a kernel wrote must be in memory when
+// it ends; left dirty (a plain store) the outputs are flushed in one burst at the end of the kernel, which the next kernel of the
+// stream waits for.  Measured inside bench.py's step (scripts/gpu_bench_ab.sh, same box, two rounds): ChannelNorm backward 11.4 ->
+// 9.7 us, forward 8.0 -> 7.5, Resample2d forward 21.7 -> 21.4, step 0.1976 -> 0.1953 ms (non-temporal stores instead: 0.1948, but
+// ChannelNorm forward 8.6 us); the correlation kernels' rows carry the same hint on their buffer stores (-5 % of the step).
+template <class V> __device__ __forceinline__ void store_out(V *p, V v)
+{
+#if defined(FN2_ABL_OUTTEMPORAL)   // timing ablation: plain stores
+    *p = v;
+#elif defined(FN2_ABL_OUTNT)       // timing ablation: non-temporal stores
+    __builtin_nontemporal_store(v, p);
+#else
+    // (s_nop: a store of more than 64 bits needs a wait state before its data registers may be overwritten; the compiler
+    // provides it for its own instructions, not for inline assembly -- cf. correlation_f16x2.hip)
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (sizeof(V) == 4) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+#endif
+}
+
 // XCD-aware remap of a 1-D block index: consecutive logical tiles land on the same XCD
 // (hardware dispatches block b to XCD b % 8), so neighbouring tiles share one L2.
 // Bijective for any grid size (cdna guide 5 "XCD swizzle must be bijective").

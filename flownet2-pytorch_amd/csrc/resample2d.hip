@@ -442,15 +442,15 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
             } else {
                 val = i00;
             }
-            if (!FUSE) out[((long)b * C + c) * HW + (y * W + x)] = val;
+            if (!FUSE) store_out(out + ((long)b * C + c) * HW + (y * W + x), val);
             else {
                 const int pix = y * W + x;
                 float *ob = out + (long)b * (3 * C + 3) * HW + pix;
                 const float v0 = pair[((long)b * 2 * C + c) * HW + pix];
                 const float v1 = wc[(y - wy0) * WW + (x - wx0)];        // the pixel itself is always inside the window
-                ob[(long)c * HW] = v0;
-                ob[(long)(C + c) * HW] = v1;
-                ob[(long)(2 * C + c) * HW] = val;
+                store_out(ob + (long)c * HW, v0);
+                store_out(ob + (long)(C + c) * HW, v1);
+                store_out(ob + (long)(2 * C + c) * HW, val);
                 const float d = v0 - val;                               // models.py:134
                 ssq[k] = ssq[k] + d * d;                                // channelnorm_kernel.cu:47-50
             }
@@ -468,9 +468,9 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
             float *ob = out + (long)b * (3 * C + 3) * HW + pix;
             // models.py:138 `flow / self.div_flow` on a GPU tensor: PyTorch multiplies by the fp32 reciprocal of a scalar divisor
             const float inv_div = 1.0f / div_flow;
-            ob[(long)(3 * C) * HW] = flow[(long)b * 2 * HW + pix] * inv_div;
-            ob[(long)(3 * C + 1) * HW] = flow[(long)b * 2 * HW + HW + pix] * inv_div;
-            ob[(long)(3 * C + 2) * HW] = __fsqrt_rn(ssq[k]);                                // channelnorm_kernel.cu:52
+            store_out(ob + (long)(3 * C) * HW, flow[(long)b * 2 * HW + pix] * inv_div);
+            store_out(ob + (long)(3 * C + 1) * HW, flow[(long)b * 2 * HW + HW + pix] * inv_div);
+            store_out(ob + (long)(3 * C + 2) * HW, __fsqrt_rn(ssq[k]));                      // channelnorm_kernel.cu:52
         }
     }
 }
@@ -645,8 +645,8 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
         const long p = (long)y * W + x;
-        gflow[(long)b * 2 * HW + p] = out_dx[k];
-        gflow[(long)b * 2 * HW + HW + p] = out_dy[k];
+        store_out(gflow + (long)b * 2 * HW + p, out_dx[k]);
+        store_out(gflow + (long)b * 2 * HW + HW + p, out_dy[k]);
     }
 }
 
