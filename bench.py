@@ -579,8 +579,8 @@ def main():
             "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1), **cold,
                     "note": "probes of THIS box: a register-only f16 MFMA stream on every SIMD (first / last five of 40 back-to-back launches; dense "
                             "peak 2500), the streaming copy, and the graded kernel timed alone (operands cache-resident / after a 1 GiB "
-                            "fill).  About every second box of the pool runs the whole step 20 % slower (0.245-0.26 vs 0.205-0.21 ms, "
-                            "eager and as a hipGraph alike) although all of these probes agree within a few percent across boxes "
+                            "fill).  About every second box of the pool runs the whole step 20 % slower (0.23-0.24 vs 0.195-0.205 ms at the "
+                            "closing build of round 3, eager and as a hipGraph alike) although all of these probes agree within a few percent across boxes "
                             "(DESIGN.md 5)"},
         }
         assert len(per_rank) == world and all(r["finite"] for r in per_rank), per_rank
