@@ -10,6 +10,8 @@ reference's own functions):
 
 ``writeFlow`` forms the interleaved float32 image in one pass instead of a float64 scratch matrix filled by two strided
 assignments (:51-54; the detour through float64 is exact for float32 and float64 inputs alike, so the bytes agree).
+``flow2img`` / ``compute_color`` / ``make_color_wheel`` / ``visulize_flow_file`` (the reference's spelling) are its Middlebury
+colour coding of a flow field (:62-204), value for value (tests/test_flo.py against images made by the reference's functions).
 ``save_flows`` is what the reference's inference loop does per batch (main.py:385-389: one ``.data.cpu().numpy()``
 + transpose + writeFlow per item): the batch is interleaved on the device and crosses PCIe once.
 """
@@ -76,3 +78,69 @@ def save_flows(folder, flows, start_index=0, pattern="%06d.flo"):
             host[i].tofile(f)
         paths.append(path)
     return paths
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Middlebury colour coding (reference utils/flow_utils.py:62-204): direction -> hue on a 55-entry colour wheel, magnitude
+# (relative to the largest in the image) -> saturation.  Whole-array numpy, all three channels at once; the arithmetic and
+# its order are the reference's, so the uint8 images are identical.
+_WHEEL_SEGMENTS = (          # (entries, channel held at 255, channel that ramps, ramp rises?)   RY YG GC CB BM MR  (:162-167)
+    (15, 0, 1, True), (6, 1, 0, False), (4, 1, 2, True), (11, 2, 1, False), (13, 2, 0, True), (6, 0, 2, False))
+
+
+def make_color_wheel():
+    """55 x 3 float64 table of (R, G, B) in 0..255 (:157-204)."""
+    wheel = np.zeros((sum(seg[0] for seg in _WHEEL_SEGMENTS), 3))
+    row = 0
+    for n, fixed, ramp, rising in _WHEEL_SEGMENTS:
+        steps = np.floor(255 * np.arange(0, n) / n)
+        wheel[row:row + n, fixed] = 255
+        wheel[row:row + n, ramp] = steps if rising else 255 - steps
+        row += n
+    return wheel
+
+
+def compute_color(u, v):
+    """Colour image (H, W, 3; float64 holding uint8 values, like the reference's) of the normalised flow components u, v
+    (:112-154).  Unlike the reference the arguments are not edited."""
+    nan = np.isnan(u) | np.isnan(v)
+    u = np.where(nan, 0, u)
+    v = np.where(nan, 0, v)
+    wheel = make_color_wheel()
+    ncols = wheel.shape[0]
+    rad = np.sqrt(u ** 2 + v ** 2)
+    fk = (np.arctan2(-v, -u) / np.pi + 1) / 2 * (ncols - 1) + 1          # 1 .. ncols: position on the wheel
+    k0 = np.floor(fk).astype(int)
+    k1 = np.where(k0 + 1 == ncols + 1, 1, k0 + 1)
+    f = (fk - k0)[..., None]
+    col = (1 - f) * (wheel[k0 - 1] / 255) + f * (wheel[k1 - 1] / 255)    # (H, W, 3)
+    inside = (rad <= 1)[..., None]
+    col = np.where(inside, 1 - rad[..., None] * (1 - col), col * 0.75)
+    return np.uint8(np.floor(255 * col * (1 - nan)[..., None])).astype(np.float64)
+
+
+def flow2img(flow_data):
+    """(H, W, 2) flow -> (H, W, 3) uint8 colour image (:72-109).  Components beyond 1e7 in magnitude mark unknown flow
+    (black).  The reference zeroes those entries in the caller's array; this function leaves ``flow_data`` untouched."""
+    u = np.array(flow_data[:, :, 0], copy=True)
+    v = np.array(flow_data[:, :, 1], copy=True)
+    unknown = (abs(u) > 1e7) | (abs(v) > 1e7)
+    u[unknown] = 0
+    v[unknown] = 0
+    with np.errstate(all="ignore"):                      # an all-zero flow divides 0 by 0 (nan -> black), as in the reference
+        maxrad = max(-1, np.max(np.sqrt(u ** 2 + v ** 2)))
+        eps = np.finfo(float).eps                        # a float64 scalar: float32 flows continue in float64 from here on
+        img = compute_color(u / maxrad + eps, v / maxrad + eps)
+    img[unknown] = 0
+    return np.uint8(img)
+
+
+def visulize_flow_file(flow_filename, save_dir=None):
+    """Colour image of a .flo file; with ``save_dir`` also written there as ``<name>-vis.png`` (:62-70, the reference's spelling
+    of the name).  Returns the image."""
+    img = flow2img(readFlow(flow_filename))
+    if save_dir:
+        from PIL import Image
+        base = os.path.basename(flow_filename)
+        Image.fromarray(img).save(os.path.join(save_dir, "%s-vis.png" % base[:-4]))
+    return img

@@ -72,6 +72,66 @@ def test_full_size_round_trip_and_batch_writer(tmp_path):
     assert flow_utils.readFlow(str(tmp_path / "empty.flo")).shape == (0, 5, 2)
 
 
+# ---------------------------------------------------------------- Middlebury colour coding (utils/flow_utils.py:62-204)
+FLOWVIS_CASES = ("noise_24x32", "radial_33x41", "specials_9x11", "f64_6x7", "axis_1x8")
+
+
+@pytest.mark.parametrize("case", FLOWVIS_CASES)
+def test_flow2img_matches_the_reference_images(case):
+    """Product and oracle against images produced by the reference's own flow2img (tests/golden/make_golden_flowvis.py):
+    identical uint8 values -- every direction and radius, unknown-flow markers, nan, exact zeros, float64 input."""
+    flow = np.load(os.path.join(GOLDEN, "flowvis_inputs.npz"))[case]
+    want = np.load(os.path.join(GOLDEN, "flowvis_%s.npy" % case))
+    keep = flow.copy()
+    got = flow_utils.flow2img(flow)
+    assert got.dtype == np.uint8 and got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(flow, keep, equal_nan=True)                  # unlike the reference, the argument is left alone
+    assert np.array_equal(flo_oracle.flow2img_oracle(flow), want)
+
+
+def test_color_wheel_and_edge_cases(tmp_path):
+    wheel = flow_utils.make_color_wheel()
+    assert wheel.shape == (55, 3) and np.array_equal(wheel, np.load(os.path.join(GOLDEN, "flowvis_wheel.npy")))
+    assert np.array_equal(flo_oracle.wheel_oracle(), wheel)
+    assert (flow_utils.flow2img(np.zeros((4, 5, 2), np.float32)) == 0).all()           # 0 / 0 -> nan -> black, as the reference
+    one = flow_utils.flow2img(np.array([[[3.0, 0.0]]], np.float32))                    # a single vector is its own maximum: radius 1 + eps
+    assert one.shape == (1, 1, 3) and np.array_equal(one, flo_oracle.flow2img_oracle(np.array([[[3.0, 0.0]]], np.float32)))
+    img = flow_utils.compute_color(np.array([[0.5, np.nan]]), np.array([[0.0, 0.2]]))
+    assert img.dtype == np.float64 and img.shape == (1, 2, 3) and (img[0, 1] == 0).all() and (img == np.floor(img)).all()
+    # .flo file -> colour image -> PNG next to it (the reference's visulize_flow_file, its spelling)
+    flow = np.load(os.path.join(GOLDEN, "flowvis_inputs.npz"))["radial_33x41"]
+    flow_utils.writeFlow(str(tmp_path / "r.flo"), flow)
+    img = flow_utils.visulize_flow_file(str(tmp_path / "r.flo"), str(tmp_path))
+    assert np.array_equal(img, np.load(os.path.join(GOLDEN, "flowvis_radial_33x41.npy")))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "r-vis.png").convert("RGB")), img)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/utils"), reason="reference checkout not present")
+def test_flow2img_against_the_live_reference():
+    import sys
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, "/root/reference")
+    try:
+        import importlib
+        ref = importlib.import_module("utils.flow_utils") if "utils.flow_utils" not in sys.modules else None
+    finally:
+        sys.path.remove("/root/reference")
+    if ref is None or not hasattr(ref, "TAG_CHAR"):     # `utils` already resolved to the product package in this process
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_flow_utils", "/root/reference/utils/flow_utils.py")
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+    rng = np.random.default_rng(77)
+    for shape, scale in (((17, 23, 2), 1.0), ((8, 8, 2), 1e-6), ((30, 5, 2), 400.0)):
+        flow = (rng.standard_normal(shape) * scale).astype(np.float32)
+        flow[0, 0] = (5e7, 0.0)
+        with np.errstate(all="ignore"):
+            want = ref.flow2img(flow.copy())
+        assert np.array_equal(flow_utils.flow2img(flow), want)
+
+
 @pytest.mark.gpu
 def test_save_flows_from_device_tensor(tmp_path, dev):
     """The batch writer fed with a device tensor (the network's output): interleave on the GPU, one transfer, same bytes."""
