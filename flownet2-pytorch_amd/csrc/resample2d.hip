@@ -13,6 +13,8 @@
 // atomics and forms both flow-gradient components from the same loaded corners.
 // Arithmetic order follows the reference so the gather results are bit-identical to its source
 // semantics: bilinear weights in double, each term rounded to float, float accumulation.
+#include <type_traits>
+
 #include "fn2_common.h"
 #include "fn2_debug.h"
 
@@ -327,6 +329,14 @@ __device__ __forceinline__ void lds_add_f32(float *addr, float v)
     } while (old != assumed);
 }
 
+// fp64 cell += fp32 value: ds_add_f64 without return (the product was formed in fp32 as the reference forms it; the
+// conversion is exact)
+__device__ __forceinline__ void lds_add_f64(double *addr, float v)
+{
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)addr, (double)v);
+}
+__device__ __forceinline__ void lds_add_f64(float *, float) {}   // never called (ACC 0 instantiations)
+
 // FUSE (models.py:133-138): `img` is the second image of a B x 2C x H x W pair tensor `pair`, and the
 // kernel writes cat((pair, warped, flow / div_flow, ||pair[:, :C] - warped||_2), 1) = B x (3C+3) x H x W in one pass:
 // the warped channel, the copy of both images (the second one comes from the LDS window), the squared difference
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
     }
 }
 
-template <int TH, int TW, int R, int NT, int WPE>
+template <int TH, int TW, int R, int NT, int WPE, int ACC = 0>
 __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
                                                             const float *__restrict__ flow,
                                                             const float *__restrict__ gout,
@@ -489,7 +499,11 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     // reference's expressions.
     constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT;
     __shared__ __attribute__((aligned(16))) float iwin[WH * WW];   // image window
-    __shared__ float awin[WH * WWP];                               // accumulation window (+1: rows on different banks)
+    // accumulation window (+1: rows on different banks).  ACC 0: fp32 cells, added to with a compare-and-swap loop (lds_add_f32);
+    // ACC 1: fp64 cells, added to with ds_add_f64 -- no return value, no retry loop, no round trip per add (the returning LDS
+    // atomic is what bounds the CAS loop, scripts/ubench/lds_cas_pipelined.hip); the sum is rounded to fp32 once, at the flush.
+    typedef std::conditional_t<ACC == 1, double, float> acc_t;
+    __shared__ acc_t awin[WH * WWP];
     enum { LIVE = 1, S_IN = 2, G_IN = 4, S_DX = 8, S_DY = 16, G_DX = 32, G_DY = 64 };
 
     const int tid = threadIdx.x;
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
         }
     };
     if (C > 0) win_load(img + (long)b * is.b);
-    for (int i = tid; i < WH * WWP; i += NT) awin[i] = 0.0f;
+    for (int i = tid; i < WH * WWP; i += NT) awin[i] = (acc_t)0;
     win_write();
     __syncthreads();
 
@@ -589,10 +603,17 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
             if (abl & 2) {
             } else if (fl & S_IN) {
                 const int ox = (fl & S_DX) ? 1 : 0, oy = (fl & S_DY) ? WWP : 0;
-                lds_add_f32(awin + sb, s00 * go);
-                lds_add_f32(awin + sb + ox, s01 * go);
-                lds_add_f32(awin + sb + oy, s10 * go);
-                lds_add_f32(awin + sb + oy + ox, s11 * go);
+                if constexpr (ACC == 1) {
+                    lds_add_f64(awin + sb, s00 * go);
+                    lds_add_f64(awin + sb + ox, s01 * go);
+                    lds_add_f64(awin + sb + oy, s10 * go);
+                    lds_add_f64(awin + sb + oy + ox, s11 * go);
+                } else {
+                    lds_add_f32(awin + sb, s00 * go);
+                    lds_add_f32(awin + sb + ox, s01 * go);
+                    lds_add_f32(awin + sb + oy, s10 * go);
+                    lds_add_f32(awin + sb + oy + ox, s11 * go);
+                }
             } else {
                 const int ox = (fl & S_DX) ? 1 : 0, oy = (fl & S_DY) ? Wi : 0;
                 unsafeAtomicAdd(G + sb, s00 * go);
@@ -627,10 +648,10 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
 #pragma unroll 2
             for (int i = tid; i < WH * WW; i += NT) {
                 const int gx = wx0 + lx, gy = wy0 + ly;
-                const float v = awin[ly * WWP + lx];
-                if (v != 0.0f) {
-                    awin[ly * WWP + lx] = 0.0f;
-                    if (!(abl & 1) && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) unsafeAtomicAdd(G + gy * Wi + gx, v);
+                const acc_t v = awin[ly * WWP + lx];
+                if (v != (acc_t)0) {
+                    awin[ly * WWP + lx] = (acc_t)0;
+                    if (!(abl & 1) && gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) unsafeAtomicAdd(G + gy * Wi + gx, (float)v);
                 }
                 ly += NT / WW; lx += NT % WW;
                 if (lx >= WW) { lx -= WW; ++ly; }
@@ -818,18 +839,24 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
         constexpr int TW = 64;
         const int abl = (bilinear >> 9) & 7;   // bits 9-11 of `bilinear`: profiling switches, 0 from the bindings
         const int tiles_x = (W + TW - 1) / TW;
-#define FN2_RB(TH)                                                                                                     \
+#define FN2_RB(TH, R, WPE, ACC)                                                                                        \
     do {                                                                                                               \
         const int tiles_y = (H + TH - 1) / TH;                                                                         \
-        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, 16, 1024, 8>), dim3((unsigned)((long)B * tiles_x * tiles_y)),   \
+        hipLaunchKernelGGL((resample_bwd_tiled<TH, TW, R, 1024, WPE, ACC>), dim3((unsigned)((long)B * tiles_x * tiles_y)), \
                            dim3(1024), 0, s, img, is, flow, grad_out, grad_img, grad_flow, C, Hi, Wi, H, W, tiles_x,   \
                            tiles_y, abl);                                                                              \
     } while (0)
-        switch ((bilinear >> 12) & 3) {        // bits 12-13: tile height (profiling: 1 = 48, 2 = 32, 3 = 64), 0 = automatic
-        case 1: FN2_RB(48); break;
-        case 2: FN2_RB(32); break;
-        case 3: FN2_RB(64); break;
-        default: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48); else FN2_RB(32); break;
+        // bits 12-13: tile height (profiling: 1 = 48, 2 = 32, 3 = 64), 0 = automatic; bits 14-15: accumulation window
+        // (profiling: 1 = fp64 cells 48 x 64 +- 12, 2 = fp64 cells 32 x 64 +- 16, 3 = fp64 cells 48 x 64 +- 16, one workgroup per CU)
+        switch ((bilinear >> 12) & 15) {
+        case 1: FN2_RB(48, 16, 8, 0); break;
+        case 2: FN2_RB(32, 16, 8, 0); break;
+        case 3: FN2_RB(64, 16, 8, 0); break;
+        case 4: FN2_RB(48, 12, 8, 1); break;
+        case 8: FN2_RB(32, 16, 8, 1); break;
+        case 12: FN2_RB(48, 16, 4, 1); break;
+        case 5: FN2_RB(48, 12, 8, 0); break;
+        default: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48, 16, 8, 0); else FN2_RB(32, 16, 8, 0); break;
         }
 #undef FN2_RB
     } else {

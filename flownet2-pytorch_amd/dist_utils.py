@@ -15,14 +15,20 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (set by
-    torch.distributed.run).  Returns (rank, world, local_rank); a single process needs no group."""
+    torch.distributed.run).  Returns (rank, world, local_rank); a single process needs no group --
+    unless `force` (or FN2_DIST_FORCE_GROUP=1) asks for a one-rank group, which sends every collective
+    below through the backend all the same (the 1-GPU boxes' way of executing the RCCL call sites)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("FN2_DIST_FORCE_GROUP") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
@@ -56,7 +62,7 @@ def broadcast_state(module_or_tensors, src=0):
     """One-time broadcast of parameters/buffers from `src` (the reference's DataParallel re-broadcasts
     them every forward).  Accepts an nn.Module or an iterable of tensors; a single flat buffer per
     dtype keeps it to a few large collectives (xGMI is per-link bound: few, big messages)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return
     if isinstance(module_or_tensors, torch.nn.Module):
         tensors = [p.data for p in module_or_tensors.parameters()] + [b.data for b in module_or_tensors.buffers()]
@@ -77,7 +83,7 @@ def broadcast_state(module_or_tensors, src=0):
 
 def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (step time is the slowest rank's)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -85,7 +91,7 @@ def max_over_ranks(value, device=None):
 
 
 def sum_over_ranks(value, device=None):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -23,6 +23,9 @@ class BucketedGradAllReduce:
     def __init__(self, module, bucket_bytes=48 << 20, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # a group of ONE rank still sends every bucket through the backend (how the 1-GPU boxes execute the RCCL path);
+        # only a process without any group skips the collectives
+        self.collective = dist.is_initialized()
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
@@ -70,7 +73,7 @@ class BucketedGradAllReduce:
 
     def _launch(self, i):
         flat = self.buckets[i]["flat"]
-        if self.world == 1:
+        if not self.collective:
             return
         if self.on_gpu:
             ready = torch.cuda.Event()
@@ -105,7 +108,7 @@ class BucketedGradAllReduce:
                 self._launch(i)
         for _, work in self._handles:
             work.wait()
-        if self.on_gpu and self.world > 1:
+        if self.on_gpu and self.collective:
             torch.cuda.current_stream(self.device).wait_stream(self._stream)
         if self.world > 1:
             for b in self.buckets:
