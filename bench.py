@@ -197,6 +197,113 @@ def cpu_baseline(max_seconds=30.0):
     }
 
 
+# ---- the fastest reasonable CPU formulation of the same step (SURVEY.md 8d "no sandbagging"): whole-array PyTorch on all
+# host cores -- 441 shifted channel contractions with EXPLICIT backward passes for the correlation, grid_sample (border,
+# align_corners: the closed form of resample2d_kernel.cu:15-72) and its autograd for the warp, the L2 norm
+# and its closed-form gradient.  Tolerance-level equal to the oracle (tests/test_bench_cpu_fast.py), not bit-exact: the
+# summation order is whatever the vectorised kernels choose.
+def torch_corr_fwd(a, b, md=20, s2=2):
+    B, C, H, W = a.shape
+    r = md // s2
+    D = 2 * r + 1
+    bp = torch.nn.functional.pad(b, (md, md, md, md))
+    out = a.new_empty(B, D * D, H, W)
+    for tj in range(D):
+        for ti in range(D):
+            out[:, tj * D + ti] = torch.einsum("bchw,bchw->bhw", a, bp[:, :, s2 * tj:s2 * tj + H, s2 * ti:s2 * ti + W]) / C
+    return out
+
+
+def torch_corr_bwd(a, b, go, md=20, s2=2):
+    B, C, H, W = a.shape
+    r = md // s2
+    D = 2 * r + 1
+    bp = torch.nn.functional.pad(b, (md, md, md, md))
+    g1 = torch.zeros_like(a)
+    g2p = torch.zeros_like(bp)
+    for tj in range(D):
+        for ti in range(D):
+            g = go[:, tj * D + ti].unsqueeze(1)
+            ys, xs = slice(s2 * tj, s2 * tj + H), slice(s2 * ti, s2 * ti + W)
+            g1.addcmul_(g, bp[:, :, ys, xs])
+            g2p[:, :, ys, xs].addcmul_(g, a)
+    return g1 / C, g2p[:, :, md:md + H, md:md + W] / C
+
+
+def torch_resample_grid(flow):
+    B, _, H, W = flow.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=flow.dtype), torch.arange(W, dtype=flow.dtype), indexing="ij")
+    gx = (xs + flow[:, 0]) * (2.0 / max(W - 1, 1)) - 1.0
+    gy = (ys + flow[:, 1]) * (2.0 / max(H - 1, 1)) - 1.0
+    return torch.stack((gx, gy), dim=-1)
+
+
+def torch_resample_fwd(img, flow):
+    return torch.nn.functional.grid_sample(img, torch_resample_grid(flow), mode="bilinear", padding_mode="border", align_corners=True)
+
+
+def torch_resample_bwd(img, flow, gw):
+    img = img.detach().requires_grad_(True)
+    flow = flow.detach().requires_grad_(True)
+    return torch.autograd.grad(torch_resample_fwd(img, flow), (img, flow), gw)
+
+
+def torch_chnorm_fwd(x):
+    return x.square().sum(1, keepdim=True).sqrt()
+
+
+def torch_chnorm_bwd(x, n, gn):
+    return gn * x / (n + 1e-9)
+
+
+def cpu_baseline_fast(max_seconds=15.0):
+    """The same whole steps (batch 8) in vectorised PyTorch on every host core, median of what fits the time budget."""
+    nthreads_before = torch.get_num_threads()
+    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        g = torch.Generator().manual_seed(0)
+        c, i = CORR, IMG
+        nb = c["B"]
+        a = torch.randn(nb, c["C"], c["H"], c["W"], generator=g)
+        b = torch.randn(nb, c["C"], c["H"], c["W"], generator=g)
+        go = torch.randn(nb, 441, c["H"], c["W"], generator=g)
+        img = torch.rand(nb, 3, i["H"], i["W"], generator=g) - 0.5
+        flow = torch.randn(nb, 2, i["H"], i["W"], generator=g) * 4
+        gw = torch.randn(nb, 3, i["H"], i["W"], generator=g)
+        gn = torch.randn(nb, 1, i["H"], i["W"], generator=g)
+
+        def one_step():
+            with torch.no_grad():
+                torch_corr_fwd(a, b)
+                torch_corr_bwd(a, b, go)
+                w = torch_resample_fwd(img, flow)
+                n = torch_chnorm_fwd(w)
+                torch_chnorm_bwd(w, n, gn)
+            torch_resample_bwd(img, flow, gw)
+
+        t0 = time.perf_counter()
+        one_step()
+        warm = time.perf_counter() - t0
+        times = []
+        budget = max(0.0, max_seconds - warm)
+        while True:
+            t0 = time.perf_counter()
+            one_step()
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 9 or sum(times) + times[-1] > budget:
+                break
+        med = sorted(times)[len(times) // 2]
+        return {"value": round(nb / med, 3), "unit": "image-pairs/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"{len(times)} whole steps of the same workload (batch 8) after 1 warm-up step, median; fp32; vectorised PyTorch "
+                          f"{torch.__version__} with torch.set_num_threads({os.cpu_count()}): 441 shifted channel contractions + explicit "
+                          "backward (correlation), grid_sample border/align_corners + autograd (warp), closed-form norm gradient -- the "
+                          "fastest reasonable CPU formulation (the reference has no CPU path); `cpu_baseline` beside it is the bit-exact "
+                          "scalar restatement",
+                "seconds_per_step": round(med, 4)}
+    finally:
+        torch.set_num_threads(nthreads_before)
+
+
 def flownet2c_pass(dev, rank, world, steps, warmup):
     """the whole FlowNet2C network (harness/) around the HIP layers, bs 8 per GPU at
     384x512, synthetic data, fp32: training step (forward, MultiScale-L1 loss, backward with overlapped bucketed RCCL

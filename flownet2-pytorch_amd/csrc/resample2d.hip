@@ -517,6 +517,43 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     // per-pixel state (flow is read once)
     float alpha[PPT], beta[PPT], gam_x[PPT], gam_y[PPT], out_dx[PPT], out_dy[PPT];
     int sbase[PPT], gbase[PPT], flags[PPT];
+    // image-window staging: a thread owns NW 4-px groups; loaded to registers (so the loads of channel c+1 are in flight
+    // while channel c's accumulation window is flushed), then written to LDS
+    constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
+    f4 wreg[NW];
+    auto win_load = [&](const float *I) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int i = tid + NT * j;
+            asm volatile("" : "+v"(i));    // keep the address arithmetic inside the channel loop (register budget)
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            // Wi % 4 == 0 (launcher): a 4-px group is entirely inside or outside the image
+            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                v = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
+            wreg[j] = v;
+        }
+    };
+    auto win_write = [&]() {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + 4 * i) = wreg[j];
+        }
+    };
+    // all flow values of the thread are requested before the first one is used (one memory round trip instead of PPT), and
+    // the first image window right behind them: none of these addresses depends on the flow
+    float fdx[PPT], fdy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        const bool in = (x < W) && (y < H);
+        const long p = in ? (long)y * W + x : 0;
+        fdx[k] = flow[(long)b * 2 * HW + p]; fdy[k] = flow[(long)b * 2 * HW + HW + p];
+    }
+    if (C > 0) win_load(img + (long)b * is.b);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
@@ -527,8 +564,7 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
         flags[k] = 0;
         if (!((x < W) && (y < H))) continue;
         int fl = LIVE;
-        const long p = (long)y * W + x;
-        const float dx = flow[(long)b * 2 * HW + p], dy = flow[(long)b * 2 * HW + HW + p];
+        const float dx = fdx[k], dy = fdy[k];
         const float xf = (float)x + dx, yf = (float)y + dy;
         const float fx = floorf(xf), fy = floorf(yf);
         const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
@@ -555,32 +591,6 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // image-window staging: a thread owns NW 4-px groups; loaded to registers (so the loads of channel c+1 are in flight
-    // while channel c's accumulation window is flushed), then written to LDS
-    constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
-    f4 wreg[NW];
-    auto win_load = [&](const float *I) {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            int i = tid + NT * j;
-            asm volatile("" : "+v"(i));    // keep the address arithmetic inside the channel loop (register budget)
-            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
-            const int gy = wy0 + ly, gx = wx0 + lx;
-            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-            // Wi % 4 == 0 (launcher): a 4-px group is entirely inside or outside the image
-            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
-                v = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
-            wreg[j] = v;
-        }
-    };
-    auto win_write = [&]() {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int i = tid + NT * j;
-            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + 4 * i) = wreg[j];
-        }
-    };
-    if (C > 0) win_load(img + (long)b * is.b);
     for (int i = tid; i < WH * WWP; i += NT) awin[i] = (acc_t)0;
     win_write();
     __syncthreads();
@@ -588,16 +598,22 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     for (int c = 0; c < C; ++c) {
         const float *I = img + (long)b * is.b + (long)c * is.c;
         float *G = gimg + ((long)b * C + c) * HWi;
+        float gov[PPT];   // the channel's grad_out values of the thread: requested together (one round trip, not PPT)
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            int idx = tid + NT * k;
+            asm volatile("" : "+v"(idx));
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            gov[k] = (flags[k] & LIVE) ? gout[((long)b * C + c) * HW + (y * W + x)] : 0.0f;
+        }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             int fl = flags[k], sb = sbase[k], gb = gbase[k];
             if (!(fl & LIVE)) continue;
             // opaque to the optimiser: otherwise every corner address of every pixel is hoisted out of the channel
             // loop and the kernel no longer fits the 64 VGPRs two workgroups per CU need
-            int idx = tid + NT * k;
-            asm volatile("" : "+v"(fl), "+v"(sb), "+v"(gb), "+v"(idx));
-            const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            const float go = gout[((long)b * C + c) * HW + (y * W + x)];
+            asm volatile("" : "+v"(fl), "+v"(sb), "+v"(gb));
+            const float go = gov[k];
             const float s00 = (1 - alpha[k]) * (1 - beta[k]), s01 = alpha[k] * (1 - beta[k]);
             const float s10 = (1 - alpha[k]) * beta[k], s11 = alpha[k] * beta[k];
             if (abl & 2) {
@@ -856,6 +872,9 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
         case 8: FN2_RB(32, 16, 8, 1); break;
         case 12: FN2_RB(48, 16, 4, 1); break;
         case 5: FN2_RB(48, 12, 8, 0); break;
+        case 6: FN2_RB(96, 16, 4, 0); break;
+        case 7: FN2_RB(96, 16, 4, 1); break;
+        case 9: FN2_RB(48, 16, 4, 0); break;
         default: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48, 16, 8, 0); else FN2_RB(32, 16, 8, 0); break;
         }
 #undef FN2_RB

@@ -31,7 +31,21 @@ for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth
     for flags, lab in ((1, "fwd tiled"), (1 | 0x1000, "fwd tiled 48x64"), (1 | 0x2000, "fwd tiled 32x64"), (1 | 0x100, "fwd untiled")):
         t = timeit(lambda: lib.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
         print("   %-28s %.1f us" % (lab, t))
-    for flags, lab in ((1, "bwd tiled"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"), (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
+    ref = None
+    for flags, lab in ((1, "bwd tiled"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"),
+                       (1 | 0x5000, "bwd 48x64 +-12 f32 CAS"), (1 | 0x4000, "bwd 48x64 +-12 fp64 cells"), (1 | 0x8000, "bwd 32x64 +-16 fp64 cells"),
+                       (1 | 0xC000, "bwd 48x64 +-16 fp64, 1 WG/CU"), (1 | 0x9000, "bwd 48x64 +-16 f32, 1 WG/CU"),
+                       (1 | 0x6000, "bwd 96x64 +-16 f32, 1 WG/CU"), (1 | 0x7000, "bwd 96x64 +-16 fp64, 1 WG/CU"),
+                       (1 | 0x4000 | 0x200, "fp64 48x64+-12, no flush"), (1 | 0x4000 | 0x400, "fp64 48x64+-12, no scatter"),
+                       (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
                        (1 | 0xE00, "bwd tiled, none of them"), (1 | 0x100, "bwd untiled")):
+        def run():
+            gimg.zero_()
+            lib.fn2_debug_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, 1, flags & ~0xff, st)
         t = timeit(lambda: lib.fn2_debug_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
-        print("   %-28s %.1f us" % (lab, t))
+        tz = timeit(run)
+        run(); torch.cuda.synchronize()
+        if ref is None:
+            ref = (gimg.clone(), gflow.clone())
+        d = (float((gimg - ref[0]).abs().max()), float((gflow - ref[1]).abs().max()))
+        print("   %-28s %.1f us  (%.1f with the zero fill)   max |d grad_img| %.2e  |d grad_flow| %.2e vs the first row" % (lab, t, tz, d[0], d[1]))
