@@ -304,6 +304,55 @@ def cpu_baseline_fast(max_seconds=15.0):
         torch.set_num_threads(nthreads_before)
 
 
+def pmc_traffic(timeout=170):
+    """Fabric traffic of the graded kernel MEASURED IN THIS RUN: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass; kernel trace only alongside, as MI355X_MICROARCH.md prescribes) over a child process that launches the correlation
+    forward of the bench workload a few times through the same pybind module.  Returns (dict or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "rocprofv3 not found on this box"
+    child = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import torch, correlation_cuda\n"
+        "g = torch.Generator().manual_seed(1234)\n"
+        "a = torch.randn(%d, %d, %d, %d, generator=g).cuda(); b = torch.randn(a.shape, generator=g).cuda()\n"
+        "e = a.new_empty; s1, s2, out = e(0), e(0), e(0)\n"
+        "for _ in range(8): correlation_cuda.forward(a, b, s1, s2, out, %d, %d, %d, %d, %d, 1)\n"
+        "torch.cuda.synchronize()\n" % (ROOT, PKG, CORR["B"], CORR["C"], CORR["H"], CORR["W"], CORR["pad"], CORR["k"], CORR["md"], CORR["s1"], CORR["s2"]))
+    raw = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fn2_pmc_")
+        try:
+            subprocess.run([rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, "-c", child],
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if "corr_fwd" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        vals.append(float(r["Counter_Value"]))
+            vals = vals[2:]                      # the first launches carry the code-object load / cold caches
+            if not vals:
+                return None, f"rocprofv3 --pmc {counter}: no correlation-forward dispatches in its output"
+            raw[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:
+            return None, f"rocprofv3 --pmc {counter} failed: {exc!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # MI355X_MICROARCH.md (HBM): both counters are in KB; gfx950 tallies wide (16 B per lane) coalesced reads at HALF their bytes --
+    # the kernel's inputs arrive by 16-byte buffer loads -> FETCH_SIZE x 2; WRITE_SIZE as reported (uncalibrated)
+    read_b, write_b = 2.0 * raw["FETCH_SIZE"][0] * 1024, raw["WRITE_SIZE"][0] * 1024
+    return ({"bytes_per_launch": read_b + write_b, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+             "FETCH_SIZE_KB_raw": raw["FETCH_SIZE"][0], "WRITE_SIZE_KB_raw": raw["WRITE_SIZE"][0], "launches_averaged": raw["FETCH_SIZE"][1]},
+            "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one pass each, over a child process that launches "
+            "the same correlation forward 8 times (first 2 dropped); FETCH_SIZE x 2 per the guide's gfx950 correction, WRITE_SIZE as reported")
+
+
 def flownet2c_pass(dev, rank, world, steps, warmup):
     """the whole FlowNet2C network (harness/) around the HIP layers, bs 8 per GPU at
     384x512, synthetic data, fp32: training step (forward, MultiScale-L1 loss, backward with overlapped bucketed RCCL
@@ -381,19 +430,18 @@ def launch_plan(gpus, device_count, share):
 def self_launch(argv, gpus, share):
     """`python bench.py --gpus N` (N > 1, no torchrun): re-runs this script as N ranks, one per GPU, rank 0 inheriting stdout
     so that the ONE JSON line is its line (the reference scales with one command too: main.py:187-201).  Returns the exit code."""
-    import socket
     import subprocess
+    import tempfile
     plan, err = launch_plan(gpus, torch.cuda.device_count(), share)
     if err:
         print("[bench] " + err, file=sys.stderr, flush=True)
         return 2
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
+    # rendezvous through a fresh file (dist_utils.init_from_env, FN2_INIT_FILE): no port to lose between choosing and binding it
+    rdv_dir = tempfile.mkdtemp(prefix="fn2_bench_rdv_")
+    rdv = os.path.join(rdv_dir, "store")
     procs = []
     for env_r in plan:
-        env = dict(os.environ, **env_r, MASTER_PORT=str(port))
+        env = dict(os.environ, **env_r, FN2_INIT_FILE=rdv)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = None if env_r["RANK"] == "0" else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
@@ -418,6 +466,12 @@ def self_launch(argv, gpus, share):
             rc = rc or 124
             break
         time.sleep(0.05)
+    try:
+        if os.path.exists(rdv):
+            os.remove(rdv)
+        os.rmdir(rdv_dir)
+    except OSError:
+        pass
     return rc
 
 
@@ -428,9 +482,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a hipGraph of the step instead of launching it eagerly")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0)
-    ap.add_argument("--model", choices=("on", "off"), default="on",
-                    help="also time the whole FlowNet2C network around the layers (extra key `flownet2c`; never `value`)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-fast-seconds", type=float, default=12.0)
+    ap.add_argument("--model", choices=("auto", "on", "off"), default="auto",
+                    help="also time the whole FlowNet2C network around the layers (extra key `flownet2c`; never `value`); auto = on "
+                         "for one GPU, off for --gpus N > 1 (N ranks each running MIOpen's kernel search under the watchdog is how a "
+                         "scaling run ends with a truncated line)")
+    ap.add_argument("--pmc", choices=("auto", "on", "off"), default="auto",
+                    help="measure the graded kernel's fabric traffic in THIS run (two rocprofv3 --pmc passes over a tiny child "
+                         "process, one GPU only); auto = on where rocprofv3 is installed")
     ap.add_argument("--model-steps", type=int, default=20)
     ap.add_argument("--model-warmup", type=int, default=5)
     ap.add_argument("--model-timeout", type=float, default=240.0, help="seconds after which the FlowNet2C pass is abandoned")
@@ -538,15 +598,21 @@ def main():
         cf = kernels["corr_fwd"]
         # HBM-side traffic of the graded kernel: NOT measured in this process (PMC counters need their own rocprofv3 --pmc
         # passes, scripts/gpu_traffic.sh); the tracked result of those passes is quoted with its source
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_detail = None, None, None
+        if world == 1 and args.pmc != "off":
+            traffic_detail, traffic_src = pmc_traffic()
+            if traffic_detail is not None:
+                traffic = traffic_detail["bytes_per_launch"]
         tpath = os.path.join(ROOT, "profiles", "corr_fwd_hbm_traffic.json")
-        if os.path.exists(tpath):
+        if traffic is None and os.path.exists(tpath):
+            why_not = traffic_src
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("bytes_per_launch")
                 traffic_src = ("quoted from profiles/corr_fwd_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                "passes, FETCH_SIZE doubled per the guide's gfx950 correction; kernel source at commit "
-                               f"{tj.get('commit', 'unrecorded')}), not measured in this run")
+                               f"{tj.get('commit', 'unrecorded')}), not measured in this run"
+                               + (f" ({why_not})" if why_not else ""))
             except Exception:
                 traffic = None
         # what an event pair adds around ONE short kernel (launch latency + inter-packet gaps): a 4-byte fill
@@ -661,6 +727,8 @@ def main():
                 "frac": round(cf["achieved_GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_detail": traffic_detail,
+                "traffic_over_algorithmic": round(traffic / cf["algorithmic_bytes"], 4) if traffic else None,
                 "frac_of_copy_ceiling": round(cf["achieved_GBps"] / copy_gbs, 4),
                 "copy_ceiling_GBps": round(copy_gbs, 1),
                 "copy_ceiling_kernel": copy_kernel,
@@ -696,12 +764,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+            # the fastest reasonable CPU formulation of the same step beside the bit-exact restatement
+            try:
+                line["cpu_baseline_fast"] = cpu_baseline_fast(args.cpu_fast_seconds)
+                line["gpu_over_cpu_fast"] = round(line["value"] / line["cpu_baseline_fast"]["value"], 1)
+            except Exception as exc:
+                line["cpu_baseline_fast"] = {"error": repr(exc)}
     else:
         line = None
 
     # The whole FlowNet2C network around the layers (extra key, never `value`).  All ranks take part (gradient all-reduce);
     # a watchdog guarantees the one JSON line even if this pass stalls: it prints the hot-path line and ends the process.
-    if args.model == "on":
+    if args.model == "on" or (args.model == "auto" and world == 1):
         import threading
 
         def give_up():

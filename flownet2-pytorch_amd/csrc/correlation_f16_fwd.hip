@@ -525,6 +525,7 @@ bool corr_f16_fwd_applicable(int dtype, int C, int H, int W, int pad, int k, int
     if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md / 2 != hf::DR || (md & 1)) return false;
     if (C % (2 * hh::CKH) != 0 || (H & 1) || (W % 8) != 0) return false;
     if ((long)C * H * W * 2 >= 0x7fffffffL) return false;   // 32-bit buffer offsets per batch item
+    if ((long)hf::D * hf::D * H * W * 2 >= 0x7fffffffL) return false;   // ... of the output (cf. corr_f16x2_applicable)
     return true;
 }
 

@@ -522,6 +522,9 @@ bool corr_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int m
     if (k != 1 || s1 != 1 || s2 != 2 || pad != md || md / 2 != hf::DR || (md & 1)) return false;
     if (C % (2 * hf::CK) != 0 || C < 2 * hf::CK || (H & 1) || (W % 8) != 0) return false;   // W > 64: correlation_f16x2_wide.hip
     if ((long)C * H * W * 4 >= 0x7fffffffL) return false;   // 32-bit buffer offsets per batch item
+    // ... of the output too: the epilogue forms (tj * D * H + y) * W * 4 and D * D * H * W * 4 in 32 bits (maps wider than 64 px
+    // made this reachable: the task-table limit alone allows H * W up to ~1.6 M).  AUTO then goes on to the general kernel.
+    if ((long)hf::D * hf::D * H * W * 4 >= 0x7fffffffL) return false;
     return true;
 }
 

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     // waves scale the G operand).  Written by staging wave 0 before the last barrier of the previous task / barrier (A), read by
     // the matrix waves after it.
     __shared__ int scl_k[2];
+    // ... and, since round 4, ONE EXPONENT PER CHANNEL for the X operand: kx[task parity][channel of the task].  X is the A matrix of
+    // the products (rows = channels): a per-row scale leaves through the rows of D, i.e. per gradient channel, exactly.  With one
+    // exponent per task, channels 1000 x smaller than the task's typical magnitude kept 13 bits (their residual term went
+    // f16-subnormal): tests/test_gpu_parity.py::test_correlation_backward_per_channel_error.  scl_k[0] is unused now.
+    __shared__ int scl_kx[2][CG];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     // row ai = g, wave w owns channels w, w + NWAVES, ... (scalars): the LDS offset is a lane part + 1 KB per channel, the global
     // row a buffer store with one lane offset and a scalar channel offset.
     // ksum = kx + kg: the matrix-core sums carry 2^ksum (the operand scales of the task); removed with the 1/C, exactly
-    auto store_rows = [&](const Task &tk, int ksum) {
+    auto store_rows = [&](const Task &tk, int kg, int par) {   // kg: the task's G exponent; par: which half of scl_kx holds its X exponents
         int ln = lane;
         asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
         const int g = ln >> 4, xg = 4 * (ln & 15);
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         // just issued: the hardware needs a wait state there that the compiler does not insert for inline assembly.)
         float f = 1.0f;
         if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
-        const int kx_mm = -ksum - lgC, kx_ex = -lgC;   // matrix-core sums / sums of the fp32 fallback
+        const int kx_ex = -lgC;   // sums of the fp32 fallback (the matrix-core sums of channel c also carry 2^(kx[c] + kg))
+        auto ksum_of = [&](int c) { return to_sgpr(scl_kx[par][c & (CG - 1)]) + kg; };
         auto scaled = [&](f4 val, int kx) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = __builtin_ldexpf(val[e], kx);
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                  __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
             if (!(VAR & 4))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), BWD_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], -ksum_of(c) - lgC)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), BWD_STORE_AUX);
         }
         // Non-finite values (an operand beyond the f16 range): a second pass recomputes exactly those outputs with an fp32 fma
         // chain and stores the row again.  Kept out of the loop above: inlined there, its live state pushes the row values
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             for (int i = 0; i < NRI; ++i) {
                 if (!(bad >> i & 1)) continue;
                 const int c = chan(i);
+                const int ksum = ksum_of(c);
                 f4 val = read_row(c);
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
@@ -344,10 +351,15 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
 #pragma unroll
             for (int k = 0; k < XK; ++k) x_issue1(L, tk, u, ch, k);
         };
-        f16s::scale2_t sc_x = f16s::scale2_from_exp(0);   // the current task's X scale (SGPR pair)
-        auto x_write1 = [&](const XSet &L, char *buf, int k) {
+        // the current task's X scales: one per channel, i.e. per item of a lane (channel 32 ch + 8 k + s_ch): read from the LDS table
+        // where they are used (as registers across the u loop they push the staging waves into scratch)
+        auto x_write1 = [&](const XSet &L, char *buf, int k, float sc) {
             if (VAR & 16) { asm volatile("" ::"v"(L.v[k][0]), "v"(L.v[k][1])); return; }
-            const f4 x0 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][0]), sc_x), x1 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][1]), sc_x);
+#ifdef FN2_ABL_NOMUL
+            const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]), x1 = __builtin_bit_cast(f4, L.v[k][1]); (void)sc;
+#else
+            const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]) * sc, x1 = __builtin_bit_cast(f4, L.v[k][1]) * sc;   // power of two: exact
+#endif
             char *dst = buf + w_ofs + k * 2 * NSW * CHS;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         // EVERY staging wave loads the same values and derives the same two exponents: no exchange, no barrier.  Requested at the
         // start of the previous task's last MFMA phase, evaluated while the matrix waves scatter that task's accumulators.
         constexpr int U0 = 2;
-        struct Samp { u2 x, g; };
+        struct Samp { u2 x, x2, g; };   // X: lane = channel of the task, 4 values of it (two rows, two places); G: as before
         auto sample_issue = [&](const Task &tk, Samp &S) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -381,24 +393,35 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const int c = tk.cg * CG + ln, ilx = 4 * tk.rg - DR + 4 * U0 + (ln & 3);
             const int ti = (5 * q + (ln & 3) + bi) % D;
             const unsigned ox = (ilx >= 0 && ilx < HL) ? (unsigned)((c * HW + (long)(2 * ilx + tk.py) * p.W + x) * 4) : 0x80000000u;
+            const int ilx2 = 4 * tk.rg - DR + 4 * U0 + ((ln + 2) & 3), xb = (x + (p.W >> 1)) >= p.W ? x + (p.W >> 1) - p.W : x + (p.W >> 1);
+            const unsigned ox2 = (ilx2 >= 0 && ilx2 < HL) ? (unsigned)((c * HW + (long)(2 * ilx2 + tk.py) * p.W + xb) * 4) : 0x80000000u;
             const unsigned og = (ilg >= 0 && ilg < HL) ? (unsigned)((((tj * D + ti) * p.H + 2 * ilg + tk.py) * p.W + x) * 4) : 0x80000000u;
 #ifdef FN2_ABL_NOSAMPLELOAD   // timing ablation
-            S.x = (u2)0x3f000000u; S.g = (u2)0x3f000000u; (void)ox; (void)og;
+            S.x = (u2)0x3f000000u; S.x2 = S.x; S.g = (u2)0x3f000000u; (void)ox; (void)ox2; (void)og;
 #else
             S.x = (VAR & 2) ? (u2)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox, 0, 0);
+            S.x2 = (VAR & 2) ? (u2)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox2, 0, 0);
             S.g = (VAR & 2) ? (u2)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b64(rsg, (int)og, 0, 0);
 #endif
         };
+        // kx: THIS LANE'S channel -- the largest of its four sampled values lands in [1, 2) (typical values around 2^-1, where the
+        // mean-exponent rule of f16x2_split.h puts them; no non-zero sample: no scaling); kg: one exponent for the task, as before
         auto sample_scales = [&](const Samp &S, int &kx, int &kg) {
-            const unsigned tx = exp_stat(S.x[0]) + exp_stat(S.x[1]), tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
-            kx = scale_exp(wave_sum(tx));
+            const unsigned e0 = (S.x[0] >> 23) & 0xffu, e1 = (S.x[1] >> 23) & 0xffu, e2 = (S.x2[0] >> 23) & 0xffu, e3 = (S.x2[1] >> 23) & 0xffu;
+            const unsigned em = max(max(e0, e1), max(e2, e3));
+            const int k = 127 - (int)em;
+            kx = em == 0u ? 0 : (k < -126 ? -126 : k);
+            const unsigned tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
             kg = scale_exp(wave_sum(tg));
         };
-        auto publish = [&](int kx, int kg) { if (tid == 0) { scl_k[0] = kx + kg; scl_k[1] = kg; } };
+        auto publish = [&](int par, int kx, int kg) {
+            if (wave == 0) { scl_kx[par][lane] = kx; if (lane == 0) scl_k[1] = kg; }
+        };
         XSet XA0, XA1, XB0, XB1;
         int t = (int)xcd_remap(blockIdx.x, gridDim.x);
         Samp SM;
-        int kx_n = 0, kg_n = 0;                                // the next task's scale exponents
+        int kx_n = 0, kg_n = 0;                                // the next task's scale exponents (kx: of this lane's sample channel)
+        int it = 0;                                            // tasks done by this workgroup: parity selects the half of scl_kx
         if (t < ntasks) {
             const Task tk = get_task(t);
             sample_issue(tk, SM);
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             dma_wait();
             stamp(2);
             sample_scales(SM, kx_n, kg_n);
-            publish(kx_n, kg_n);
+            publish(0, kx_n, kg_n);
         }
         __syncthreads();                                       // (A) G(0) complete, the first task's exponents published
         stamp(3);
@@ -418,17 +441,17 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const bool has_next = t + (int)gridDim.x < ntasks;
             const Task tn = get_task(has_next ? t + (int)gridDim.x : t);
             const bool first = t < (int)gridDim.x;
-            const int ksum = kx_n + kg_n;
-            sc_x = f16s::scale2_from_exp(kx_n);
+            const int kg_cur = kg_n, par = it & 1;
+            auto sxf = [&](int ch, int k) { return f16s::scale_from_exp(scl_kx[par][ch * CK + 2 * NSW * k + s_ch]); };
             auto one_u = [&](int u, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
                 // phase 1 (the matrix waves gather the G operands of u): request the next X chunks, write both X chunks of u
                 // (all loads first: interleaving them with the items of x_write measured 4 us slower)
                 if (u + 1 < NU) { x_issue(N0, tk, u + 1, 0); x_issue(N1, tk, u + 1, 1); }
                 else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
 #pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k);
+                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k, sxf(0, k));
 #pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, k);
+                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, k, sxf(1, k));
                 if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 if (first && u < 2) stamp(5 + 4 * u);
@@ -446,13 +469,14 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             }
             // while the matrix waves scatter their accumulators: the next task's scale exponents (every wave has read the current
             // ones: the matrix waves do at the top of the task)
-            if (has_next) { sample_scales(SM, kx_n, kg_n); publish(kx_n, kg_n); }
+            if (has_next) { sample_scales(SM, kx_n, kg_n); publish(par ^ 1, kx_n, kg_n); }
             if (first) stamp(12);
             __syncthreads();                                   // epilogue image (over the X buffers) complete
             if (first) stamp(13);
-            store_rows(tk, ksum);
+            store_rows(tk, kg_cur, par);
             __syncthreads();                                   // image read: the X buffers are free for the next task
             if (first) stamp(14);
+            ++it;
         }
         stamp(15);
         dump();
@@ -466,10 +490,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
 
+    int itm = 0;   // tasks done by this workgroup (parity: which half of scl_kx holds the current task's X exponents)
     auto run_task = [&](const Task &tk, auto flipc, bool first) {
         constexpr int FLIP = decltype(flipc)::value;
-        const int ksum = to_sgpr(scl_k[0]);                     // published before the barrier this wave just passed
-        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(to_sgpr(scl_k[1]));
+        const int kg_cur = to_sgpr(scl_k[1]);                   // published before the barrier this wave just passed
+        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(kg_cur);
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int f_i = ln & 15, f_g = ln >> 4;                 // pixel / channel index, k group
@@ -655,13 +680,13 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         }
         __syncthreads();
         if (first) stamp(13);
-        store_rows(tk, ksum);
+        store_rows(tk, kg_cur, itm & 1);
         __syncthreads();
         if (first) stamp(14);
     };
     __syncthreads();                                           // (A) G(0) of the first task complete, its scale exponents published
     stamp(3);
-    for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
+    for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x, ++itm) {
         const Task tk = get_task(t);
         const bool first = t < (int)gridDim.x;
         if (tk.flip) run_task(tk, std::integral_constant<int, 1>{}, first);

@@ -17,7 +17,7 @@
 //   - values down to 2^-(3 + T_GEO) = 1/4 of the typical magnitude keep >= 22 bits, smaller ones an absolute error of
 //     2^-(25 + T_GEO) = 2^-24 of it: fp32-class sums at any input magnitude (measured: 0.65 x the fp32 MFMA kernel's error
 //     against fp64 from 2^-27 to 2^13, tests/test_gpu_parity.py);
-//   - values up to 2^(16 - T_GEO) = 131072 x the typical magnitude fit; anything larger makes h infinite, the outputs it
+//   - values up to 2^(16 - T_GEO) = 2^17 = 131072 x the typical magnitude fit; anything larger makes h infinite, the outputs it
 //     touches come out non-finite and are recomputed by a plain fp32 fma chain (exact_corr / exact_grad: slow, always right).
 // The mean exponent (not the maximum) is used because a single huge element must not push everything else of the tile
 // into the f16 subnormals.  Scaling by a power of two is exact: for operands of unit magnitude the split, the products
@@ -109,8 +109,12 @@ __device__ __forceinline__ int scale_exp(unsigned packed)
     const unsigned sum = packed & 0xffffu, cnt = packed >> 16;
     if (cnt == 0u) return 0;
     const int e = (int)((float)sum * __builtin_amdgcn_rcpf((float)cnt) + 0.5f);   // mean biased exponent, 1 .. 255
-    const int k = T_GEO + 127 - to_sgpr(e);                                        // -126 .. 128
-    return k > 127 ? 127 : k;
+    const int k = T_GEO + 127 - to_sgpr(e);                                        // -129 .. 125 before clamping
+    // 2^k must be a NORMAL float for scale_from_exp / scale2_from_exp (biased exponent 127 + k in 1 .. 254): a sample around
+    // 2^126 (e = 253) would otherwise encode the scale as 0.0 -- every finite operand of the tile multiplied to zero, outputs
+    // finite and wrong --, e = 254 as -inf, e = 255 (a sample of inf / nan) as -2^127.  Clamped, such a tile is scaled by
+    // 2^-126: its largest values overflow the f16 and are recomputed by the fp32 chain, as any out-of-range operand is.
+    return k > 127 ? 127 : k < -126 ? -126 : k;
 }
 __device__ __forceinline__ float scale_from_exp(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
 __device__ __forceinline__ scale2_t scale2_from_exp(int k)   // {2^k, 2^k}

@@ -35,6 +35,11 @@ def init_from_env(backend=None, force=False):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kwargs["device_id"] = torch.device("cuda", local_rank)
+        init_file = os.environ.get("FN2_INIT_FILE")
+        if init_file:
+            # rendezvous through a file instead of a TCP port somebody else may take between choosing and binding it
+            # (bench.py's self-launch); RCCL's own bootstrap picks its sockets itself
+            kwargs.update(init_method="file://" + init_file, rank=rank, world_size=world)
         dist.init_process_group(backend, **kwargs)
     return rank, world, local_rank
 

@@ -20,24 +20,25 @@ import torch.utils.data as data
 from utils import flow_utils, frame_utils
 
 
-class StaticRandomCrop:                                    # datasets.py:13-21
-    def __init__(self, image_size, crop_size):
-        self.th, self.tw = crop_size
-        h, w = image_size
-        self.h1 = random.randint(0, h - self.th)
-        self.w1 = random.randint(0, w - self.tw)
+class _StaticCrop:
+    """A crop window chosen ONCE per sample and applied to both images and the flow (datasets.py:13-28: the reference's
+    StaticRandomCrop draws the corner at construction, StaticCenterCrop centres the window)."""
+
+    def __init__(self, image_size, crop_size, centred):
+        (h, w), (th, tw) = image_size, crop_size
+        top, left = ((h - th) // 2, (w - tw) // 2) if centred else (random.randint(0, h - th), random.randint(0, w - tw))
+        self.rows, self.cols = slice(top, top + th), slice(left, left + tw)
 
     def __call__(self, img):
-        return img[self.h1:(self.h1 + self.th), self.w1:(self.w1 + self.tw), :]
+        return img[self.rows, self.cols, :]
 
 
-class StaticCenterCrop:                                    # datasets.py:23-28
-    def __init__(self, image_size, crop_size):
-        self.th, self.tw = crop_size
-        self.h, self.w = image_size
+def StaticRandomCrop(image_size, crop_size):
+    return _StaticCrop(image_size, crop_size, centred=False)
 
-    def __call__(self, img):
-        return img[(self.h - self.th) // 2:(self.h + self.th) // 2, (self.w - self.tw) // 2:(self.w + self.tw) // 2, :]
+
+def StaticCenterCrop(image_size, crop_size):
+    return _StaticCrop(image_size, crop_size, centred=True)
 
 
 class _PairFolder(data.Dataset):

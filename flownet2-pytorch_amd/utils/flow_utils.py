@@ -32,6 +32,9 @@ def readFlow(fn):
         if len(head) < 4 or struct.unpack("<f", head[:4])[0] != TAG_FLOAT:
             print("Magic number incorrect. Invalid .flo file")
             return None
+        if len(head) < _HEADER.size:          # the tag is right but width / height are cut off
+            print("Truncated header. Invalid .flo file")
+            return None
         _, w, h = _HEADER.unpack(head)
         data = np.fromfile(f, np.float32, count=2 * int(w) * int(h))
     return np.resize(data, (int(h), int(w), 2))      # np.resize like the reference: a short file repeats its data

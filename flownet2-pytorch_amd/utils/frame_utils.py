@@ -17,5 +17,8 @@ def read_gen(file_name):
     if ext in (".bin", ".raw"):
         return np.load(file_name)
     if ext == ".flo":
-        return flow_utils.readFlow(file_name).astype(np.float32)
+        flow = flow_utils.readFlow(file_name)
+        if flow is None:
+            raise ValueError(f"{file_name}: not a Middlebury .flo file")
+        return flow.astype(np.float32)
     return []

@@ -67,9 +67,10 @@ enum {
                                 Error bound per operand, relative to the operand's typical (geometric-mean) magnitude m:
                                 max(2^-22 |x| / m, 2^-27), at ANY input magnitude (checked from 2^-27 to 2^13 and on a real
                                 training gradient, tests/test_gpu_parity.py magnitude sweeps): fp32-class sums, measured
-                                0.65x the fp32 MFMA kernel's error against fp64.  Operands above 16384 m do not fit the
-                                scaled f16; the outputs they touch are recomputed by a plain fp32 fma chain (slow, exact
-                                semantics incl. inf / nan).  Operands far BELOW m (< 2^-27 m) lose relative accuracy:
+                                0.65x the fp32 MFMA kernel's error against fp64.  m is what the scale places at 2^-1: the
+                                geometric mean of the sample's non-zero values (mean binary exponent).  Operands above
+                                2^17 m (131072 m: the f16 maximum, 2^16, over 2^-1) do not fit the scaled f16; the outputs
+                                they touch are recomputed by a plain fp32 fma chain (slow, exact semantics incl. inf / nan).  Operands far BELOW m (< 2^-27 m) lose relative accuracy:
                                 block scaling is not scale-invariant within a task, unlike the reference's fp32 products.
                                 Needs f32, k = 1, s1 = 1, s2 = 2, pad == md == 20, even H, W % 8 == 0 (any width: maps
                                 wider than 64 pixels -- Sintel-size inputs -- run column-window variants of the same kernels,

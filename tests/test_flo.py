@@ -144,3 +144,17 @@ def test_save_flows_from_device_tensor(tmp_path, dev):
         assert open(p, "rb").read() == flo_oracle.flo_bytes(flows[i].numpy().transpose(1, 2, 0))
     half = flow_utils.save_flows(str(tmp_path / "gpu16"), flows.to(dev).half())     # fp16 network output: widened, not reinterpreted
     assert open(half[2], "rb").read() == flo_oracle.flo_bytes(flows[2].half().float().numpy().transpose(1, 2, 0))
+
+
+def test_truncated_header_is_rejected(tmp_path, capsys):
+    """a right tag with width / height cut off prints the reference's kind of message and returns None (the reference
+    raises struct.error there, utils/flow_utils.py:13-21); read_gen turns None into a ValueError instead of an AttributeError."""
+    import struct
+    from utils import flow_utils, frame_utils
+    f = tmp_path / "short.flo"
+    f.write_bytes(struct.pack("<f", flow_utils.TAG_FLOAT) + b"\x05\x00")
+    assert flow_utils.readFlow(str(f)) is None
+    assert "Invalid .flo file" in capsys.readouterr().out
+    import pytest
+    with pytest.raises(ValueError):
+        frame_utils.read_gen(str(f))

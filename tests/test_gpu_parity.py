@@ -1359,3 +1359,82 @@ def test_correlation_half_special_values_and_wrapper(dev):
     assert y.dtype == torch.float16 and tuple(y.shape) == (2, 441, 12, 16)
     y.backward(torch.randn(y.shape, generator=g).half().to(dev))
     assert x1.grad.dtype == torch.float16 and torch.isfinite(x1.grad).all() and torch.isfinite(x2.grad).all()
+
+
+def _per_channel_rel(got, ref):
+    """max |err| over (batch, pixels) of each channel / max |ref| of that channel -> (C,) tensor"""
+    err = (got.double() - ref).abs().amax(dim=(0, 2, 3))
+    return err / ref.abs().amax(dim=(0, 2, 3)).clamp_min(1e-300)
+
+
+@pytest.mark.parametrize("decades", [2, 3])
+def test_correlation_backward_per_channel_error(dev, decades):
+    """Channel magnitudes spread log-uniformly over 10^-decades .. 10^+decades, independently per channel and input (FlowNetC is
+    built with batchNorm=False: nothing ties the scales of conv3's 256 channels together).  The reference forms fp32 products at
+    any scale (correlation_cuda_kernel.cu:214-229), so the error of gradInput[:, c] relative to the largest element OF THAT
+    CHANNEL must not depend on how large the other channels are: each channel within 3x of the fp32 MFMA kernel's error for it."""
+    import fn2_capi
+    B, C, H, W = 1, 256, 48, 64
+    g = torch.Generator().manual_seed(41 + decades)
+    s1 = torch.pow(10.0, (torch.rand(C, generator=g) * 2 - 1) * decades).view(1, C, 1, 1)
+    s2 = torch.pow(10.0, (torch.rand(C, generator=g) * 2 - 1) * decades).view(1, C, 1, 1)
+    x1 = (torch.randn(B, C, H, W, generator=g) * s1).to(dev)
+    x2 = (torch.randn(B, C, H, W, generator=g) * s2).to(dev)
+    go = torch.randn(B, 441, H, W, generator=g).to(dev)
+    f1, f2 = _corr_bwd_fp64(x1, x2, go)
+    q1, q2 = fn2_capi.correlation_backward(x1, x2, go, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F32)
+    for name, algo in (("f16x2", fn2_capi.FN2_CORR_MFMA_F16X2), ("auto", fn2_capi.FN2_CORR_AUTO)):
+        g1, g2 = fn2_capi.correlation_backward(x1, x2, go, 20, 1, 20, 1, 2, algo=algo)
+        for which, got, q, ref in (("gradInput1", g1, q1, f1), ("gradInput2", g2, q2, f2)):
+            e, e32 = _per_channel_rel(got, ref), _per_channel_rel(q, ref)
+            ratio = float((e / e32.clamp_min(1e-12)).max())
+            print("per-channel error, +-%d decades, %s %s: worst %.2e (fp32 MFMA %.2e), worst ratio %.2f" %
+                  (decades, name, which, float(e.max()), float(e32.max()), ratio))
+            assert float(e.max()) <= 3.0 * float(e32.max()) and ratio <= 8.0, (decades, name, which, float(e.max()), float(e32.max()), ratio)
+
+
+def test_correlation_wide_parity_at_batch_8(dev, oracle):
+    """The column-window kernels at the size scripts/wide_micro.py times them (8 x 256 x 56 x 128, Sintel conv3), against an fp64
+    formulation: fp32 forward + backward and the half forward (timed at B = 8, parity-checked only at B <= 3)."""
+    import fn2_capi
+    B, C, H, W = 8, 256, 56, 128
+    g = torch.Generator().manual_seed(77)
+    x1 = torch.randn(B, C, H, W, generator=g).to(dev)
+    x2 = torch.randn(B, C, H, W, generator=g).to(dev)
+    go = torch.randn(B, 441, H, W, generator=g).to(dev)
+    ref = _corr_fwd_fp64(x1, x2)
+    out = fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2)
+    assert _rel(out, ref) <= 2e-6, _rel(out, ref)
+    q = fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_MFMA_F32)
+    assert _rel(out, ref) <= 3.0 * _rel(q, ref)
+    f1, f2 = _corr_bwd_fp64(x1, x2, go)
+    g1, g2 = fn2_capi.correlation_backward(x1, x2, go, 20, 1, 20, 1, 2)
+    assert _rel(g1, f1) <= 2e-6 and _rel(g2, f2) <= 2e-6, (_rel(g1, f1), _rel(g2, f2))
+    for n in range(B):   # every batch item on its own (a wrong item stride would hide behind the global maximum)
+        assert _rel(out[n], ref[n]) <= 4e-6 and _rel(g1[n], f1[n]) <= 4e-6 and _rel(g2[n], f2[n]) <= 4e-6, n
+    h1, h2 = x1.half(), x2.half()
+    oh = fn2_capi.correlation_forward(h1, h2, 20, 1, 20, 1, 2)
+    rh = _corr_fwd_fp64(h1.float(), h2.float())
+    assert oh.dtype == torch.float16 and float((oh.double() - rh).abs().max()) <= 0.5 * 2.0 ** -10 * float(rh.abs().max()) * 1.01
+
+
+def test_correlation_f16x2_huge_and_tiny_operands(dev):
+    """a tile whose sample sits at 2^126 used to get the scale 2^-127 -- encoded as 0.0, every product silently 0.
+    in1 ~ 2^126 against in2 ~ 2^-126: products of order 1, as the reference computes them in fp32."""
+    import fn2_capi
+    B, C, H, W = 1, 64, 16, 24
+    g = torch.Generator().manual_seed(5)
+    m1 = (torch.rand(B, C, H, W, generator=g) + 0.5) * (torch.randint(0, 2, (B, C, H, W), generator=g) * 2 - 1)   # 0.5 <= |m1| < 1.5
+    m2 = torch.randn(B, C, H, W, generator=g)
+    x1, x2 = torch.ldexp(m1, torch.tensor(126)).to(dev), torch.ldexp(m2, torch.tensor(-126)).to(dev)
+    assert torch.isfinite(x1).all()
+    ref = _corr_fwd_fp64(m1.to(dev), torch.ldexp(x2.double(), torch.tensor(126)).float())   # what x2 holds (some of it subnormal), rescaled exactly
+    for algo in (fn2_capi.FN2_CORR_MFMA_F16X2, fn2_capi.FN2_CORR_AUTO):
+        out = fn2_capi.correlation_forward(x1, x2, 20, 1, 20, 1, 2, algo=algo)
+        assert torch.isfinite(out).all() and float(out.abs().max()) > 1e-3 and _rel(out, ref) <= 2e-6, (float(out.abs().max()), _rel(out, ref))
+    # both gradients with the inputs 2^100 apart
+    a, b = torch.ldexp(m1, torch.tensor(100)).to(dev), torch.ldexp(m2, torch.tensor(-100)).to(dev)
+    go = torch.randn(B, 441, H, W, generator=g).to(dev)
+    f1, f2 = _corr_bwd_fp64(m1.to(dev), m2.to(dev), go)
+    g1, g2 = fn2_capi.correlation_backward(a, b, go, 20, 1, 20, 1, 2)
+    assert _rel(torch.ldexp(g1.double(), torch.tensor(100)), f1) <= 2e-6 and _rel(torch.ldexp(g2.double(), torch.tensor(-100)), f2) <= 2e-6
