@@ -96,11 +96,54 @@ int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor 
     return 1;
 }
 
+// N1, training half, not in the reference module: gradients of the correlation branch of
+// cat((conv_redir, LeakyReLU(Correlation(input1, input2))), 1) (FlowNetC.py:86-87, :92).  `buffer` is the concat buffer forward_fused
+// wrote, `gradBuffer` the gradient wrt it (same shape): the slice of gradBuffer is read in place and the activation's derivative
+// comes from the sign of the stored output -- what autograd does with a contiguous copy of the slice and leaky_relu_backward.
+int correlation_backward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &buffer, at::Tensor &gradBuffer,
+                                   int channel_offset, double negative_slope, at::Tensor &gradInput1, at::Tensor &gradInput2,
+                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2)
+{
+    const char *op = "correlation_cuda.backward_fused";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    check_same(input1, buffer, op, "buffer");
+    check_same(input1, gradBuffer, op, "gradBuffer");
+    check_same(input1, gradInput1, op, "gradInput1");
+    check_same(input1, gradInput2, op, "gradInput2");
+    TORCH_CHECK(input1.dim() == 4 && input1.sizes() == input2.sizes(), op, ": inputs must be 4-D and equally shaped");
+    const int dt = dtype_of(input1, op);
+    const int B = input1.size(0), C = input1.size(1), H = input1.size(2), W = input1.size(3);
+    int nOut = 0, oH = 0, oW = 0;
+    check_rc(fn2_correlation_output_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &nOut, &oH,
+                                          &oW), op);
+    TORCH_CHECK(buffer.dim() == 4 && buffer.is_contiguous() && buffer.size(0) == B && buffer.size(2) == oH &&
+                    buffer.size(3) == oW && channel_offset >= 0 && channel_offset + nOut <= buffer.size(1),
+                op, ": buffer ", buffer.sizes(), " does not hold ", nOut, " channels of ", oH, "x", oW, " at channel ", channel_offset);
+    TORCH_CHECK(gradBuffer.sizes() == buffer.sizes(), op, ": gradBuffer ", gradBuffer.sizes(), " must have the buffer's shape ", buffer.sizes());
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor a = input1.contiguous(), b = input2.contiguous();
+    at::Tensor gb = gradBuffer.contiguous();          // what autograd hands over is contiguous already; a view would be copied here
+    gradInput1.resize_({B, C, H, W});
+    gradInput2.resize_({B, C, H, W});
+    TORCH_CHECK(gradInput1.is_contiguous() && gradInput2.is_contiguous(), op, ": gradInputs must be contiguous");
+    const size_t wsb = fn2_correlation_backward_fused_workspace_bytes(dt, B, H, W, pad_size, kernel_size, max_displacement, stride1, stride2);
+    at::Tensor ws = at::empty({(int64_t)B, (int64_t)nOut, (int64_t)oH, (int64_t)oW}, input1.options());   // caching allocator: no synchronisation
+    const int64_t off = (int64_t)channel_offset * oH * oW * buffer.element_size(), bs = buffer.size(1) * (int64_t)oH * oW;
+    check_rc(fn2_correlation_backward_fused(a.data_ptr(), b.data_ptr(), static_cast<char *>(buffer.data_ptr()) + off, bs,
+                                            static_cast<char *>(gb.data_ptr()) + off, bs, (float)negative_slope, ws.data_ptr(), wsb,
+                                            gradInput1.data_ptr(), gradInput2.data_ptr(), dt, B, C, H, W, pad_size, kernel_size,
+                                            max_displacement, stride1, stride2, FN2_CORR_AUTO, current_stream(input1)), op);
+    return 1;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "FlowNet2 correlation layer, gfx950 HIP kernels (drop-in for the reference correlation_cuda)";
     m.def("forward", &correlation_forward_hip, "Correlation forward (HIP, gfx950)");
     m.def("backward", &correlation_backward_hip, "Correlation backward (HIP, gfx950)");
     m.def("forward_fused", &correlation_forward_fused_hip,
-          "Correlation forward + LeakyReLU written into a channel slice of a concat buffer (inference)");
+          "Correlation forward + LeakyReLU written into a channel slice of a concat buffer");
+    m.def("backward_fused", &correlation_backward_fused_hip,
+          "Gradients of the correlation branch of cat((redir, LeakyReLU(corr))) from the concat gradient and the stored output");
 }

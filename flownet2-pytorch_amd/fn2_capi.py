@@ -17,6 +17,7 @@ EXPORTS = [
     "fn2_strerror", "fn2_abi_version", "fn2_correlation_output_shape",
     "fn2_correlation_forward", "fn2_correlation_forward_ex", "fn2_correlation_forward_fused",
     "fn2_correlation_backward", "fn2_correlation_backward_ex",
+    "fn2_correlation_backward_fused_workspace_bytes", "fn2_correlation_backward_fused",
     "fn2_resample2d_forward", "fn2_resample2d_backward", "fn2_warp_diff_norm_cat",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
     "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe",
@@ -46,6 +47,7 @@ def lib():
         for name in EXPORTS[1:]:
             getattr(_lib, name).restype = ctypes.c_int
         _lib.fn2_multiscale_workspace_bytes.restype = ctypes.c_size_t
+        _lib.fn2_correlation_backward_fused_workspace_bytes.restype = ctypes.c_size_t
     return _lib
 
 
@@ -129,6 +131,27 @@ def correlation_backward(in1, in2, gout, pad, k, md, s1, s2, algo=FN2_CORR_AUTO,
     with torch.cuda.device_of(in1):
         check(fn(_p(in1), _p(in2), _p(gout), _p(g1), _p(g2), _dtype_code(in1), B, C, H, W, pad, k, md, s1, s2, algo,
                  _stream(in1)), what)
+    return g1, g2
+
+
+def correlation_backward_fused(in1, in2, buffer, grad_buffer, channel_offset, negative_slope, pad, k, md, s1, s2, algo=FN2_CORR_AUTO):
+    """Gradients of the correlation branch of cat((redir, leaky_relu(corr(in1, in2)))): `buffer` is the forward's concat buffer
+    (correlation_forward_fused), `grad_buffer` the gradient wrt it, both contiguous N x Ctot x oH x oW."""
+    import torch
+    B, C, H, W = in1.shape
+    nOut, oH, oW = correlation_output_shape(H, W, pad, k, md, s1, s2)
+    assert buffer.is_contiguous() and grad_buffer.is_contiguous() and buffer.shape == grad_buffer.shape
+    es = buffer.element_size()
+    off = channel_offset * oH * oW * es
+    wsb = lib().fn2_correlation_backward_fused_workspace_bytes(_dtype_code(in1), B, H, W, pad, k, md, s1, s2)
+    ws = torch.empty(max(wsb // es, 1), dtype=in1.dtype, device=in1.device)
+    g1, g2 = torch.empty_like(in1), torch.empty_like(in2)
+    bs = ctypes.c_int64(buffer.shape[1] * oH * oW)
+    with torch.cuda.device_of(in1):
+        check(lib().fn2_correlation_backward_fused(_p(in1), _p(in2), ctypes.c_void_p(buffer.data_ptr() + off), bs,
+                                                   ctypes.c_void_p(grad_buffer.data_ptr() + off), bs, ctypes.c_float(negative_slope),
+                                                   _p(ws), ctypes.c_size_t(wsb), _p(g1), _p(g2), _dtype_code(in1), B, C, H, W,
+                                                   pad, k, md, s1, s2, algo, _stream(in1)), "fn2_correlation_backward_fused")
     return g1, g2
 
 

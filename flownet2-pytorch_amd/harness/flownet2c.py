@@ -3,9 +3,10 @@
 Module names and parameter shapes are the reference's, so a reference checkpoint's ``state_dict`` loads unchanged
 (``conv1.0.weight`` ... ``upsampled_flow3_to_2.bias``, 39 175 298 parameters; tests/test_harness.py compares the key set
 with the reference's own class where the reference checkout is present).  The cost volume is this repo's
-``Correlation`` (HIP kernels, fp32); in eval mode the LeakyReLU + concat around it are fused into the correlation's
-epilogue (``CorrelationLeakyReLUCat``), in training mode they are separate ops because the backward
-pass needs the pre-activation sign.
+``Correlation`` (HIP kernels, fp32); the LeakyReLU + concat around it are fused into the correlation's epilogue
+(``CorrelationLeakyReLUCat``) -- in training too since round 4: the backward reads the activation's derivative
+off the sign of the stored output and the gradient from its slice of the concat gradient (``fused_training=False`` keeps the
+three separate ops of FlowNetC.py:86-92).
 """
 import torch
 from torch import nn
@@ -27,9 +28,10 @@ def _act():
 
 
 class FlowNet2C(nn.Module):
-    def __init__(self, rgb_max=255.0, div_flow=20.0, batch_norm=False, fused_inference=True):
+    def __init__(self, rgb_max=255.0, div_flow=20.0, batch_norm=False, fused_inference=True, fused_training=True):
         super().__init__()
         self.rgb_max, self.div_flow, self.fused_inference = float(rgb_max), float(div_flow), fused_inference
+        self.fused_training = fused_training
         for name, cin, cout, k, s in _CONVS:       # submodules.conv: Conv2d (+ BatchNorm2d) + LeakyReLU(0.1), "same" padding
             layers = [nn.Conv2d(cin, cout, k, s, (k - 1) // 2, bias=not batch_norm)]
             if batch_norm:
@@ -62,7 +64,7 @@ class FlowNet2C(nn.Module):
     def merge(self, c3a, c3b):
         """Cost volume, LeakyReLU, concat with the redirected features (FlowNetC.py:85-92)."""
         redir = self.conv_redir(c3a)
-        if self.fused_inference and not torch.is_grad_enabled():
+        if self.fused_inference if not torch.is_grad_enabled() else self.fused_training:
             return self.corr_fused(c3a, c3b, redir)
         return torch.cat((redir, self.corr_activation(self.corr(c3a, c3b))), 1)
 

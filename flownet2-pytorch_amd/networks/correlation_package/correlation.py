@@ -60,10 +60,45 @@ class Correlation(nn.Module):
                 f"stride1={self.stride1}, stride2={self.stride2}")
 
 
+class CorrelationLeakyReLUCatFunction(Function):
+    """``cat((redir, leaky_relu(corr(input1, input2), slope)), 1)`` (FlowNetC.py:86-87, :92) as one differentiable op: forward =
+    the correlation kernel with the activation and the store into the concat buffer fused into its epilogue; backward = the
+    gradient of the buffer's correlation slice read in place, the activation's derivative taken from the sign of the stored
+    output (no mask, no saved pre-activation), the correlation backward kernels (correlation_cuda.backward_fused)."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, redir, pad_size, kernel_size, max_displacement, stride1, stride2, negative_slope):
+        n_out = ((max_displacement // stride2) * 2 + 1) ** 2
+        B, Cr, oH, oW = redir.shape
+        buf = redir.new_empty((B, Cr + n_out, oH, oW))
+        buf[:, :Cr].copy_(redir)
+        with torch.cuda.device_of(input1):
+            correlation_cuda.forward_fused(input1, input2, buf, Cr, float(negative_slope), pad_size, kernel_size,
+                                           max_displacement, stride1, stride2)
+        ctx.save_for_backward(input1, input2, buf)
+        ctx.corr_params = (pad_size, kernel_size, max_displacement, stride1, stride2)
+        ctx.channel_offset, ctx.negative_slope = Cr, float(negative_slope)
+        return buf
+
+    @staticmethod
+    def backward(ctx, grad_buf):
+        input1, input2, buf = ctx.saved_tensors
+        Cr = ctx.channel_offset
+        grad_in1 = grad_in2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            with torch.cuda.device_of(input1):
+                grad_in1, grad_in2 = input1.new_empty(0), input2.new_empty(0)
+                correlation_cuda.backward_fused(input1, input2, buf, grad_buf, Cr, ctx.negative_slope, grad_in1, grad_in2,
+                                                *ctx.corr_params)
+        grad_redir = grad_buf[:, :Cr] if ctx.needs_input_grad[2] else None
+        return (grad_in1, grad_in2, grad_redir) + (None,) * 6
+
+
 class CorrelationLeakyReLUCat(nn.Module):
-    """SURVEY.md 8f N1 (inference): ``torch.cat((redir, leaky_relu(corr(input1, input2), slope)), 1)`` with the
-    activation and the concat fused into the correlation epilogue -- the three statements FlowNetC.py:86-87,92 as one
-    kernel pass over the 441-channel cost volume instead of three.  No autograd (use ``Correlation`` for training).
+    """``torch.cat((redir, leaky_relu(corr(input1, input2), slope)), 1)`` with the activation and the concat
+    fused into the correlation epilogue -- the three statements FlowNetC.py:86-87,92 as one kernel pass over the 441-channel
+    cost volume instead of three --, and, in training, one pass instead of two in front of the correlation backward
+    (``CorrelationLeakyReLUCatFunction``).
 
         cat = CorrelationLeakyReLUCat(20, 1, 20, 1, 2, negative_slope=0.1)(out_conv3a, out_conv3b, out_conv_redir)
     """
@@ -73,13 +108,5 @@ class CorrelationLeakyReLUCat(nn.Module):
         self.corr_params = (pad_size, kernel_size, max_displacement, stride1, stride2)
         self.negative_slope = negative_slope
 
-    @torch.no_grad()
     def forward(self, input1, input2, redir):
-        pad, k, md, s1, s2 = self.corr_params
-        n_out = ((md // s2) * 2 + 1) ** 2
-        B, Cr, oH, oW = redir.shape
-        buf = redir.new_empty((B, Cr + n_out, oH, oW))
-        buf[:, :Cr].copy_(redir)
-        with torch.cuda.device_of(input1):
-            correlation_cuda.forward_fused(input1, input2, buf, Cr, float(self.negative_slope), pad, k, md, s1, s2)
-        return buf
+        return CorrelationLeakyReLUCatFunction.apply(input1, input2, redir, *self.corr_params, self.negative_slope)

@@ -136,6 +136,27 @@ int fn2_correlation_backward_ex(const void *in1, const void *in2, const void *gr
                                 int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
                                 int algo, void *stream);
 
+/* "Next" row N1, training half: the backward pass of the fused forward above -- of the correlation branch of
+ * cat((conv_redir, LeakyReLU_s(Correlation(in1, in2))), 1) (FlowNetC.py:86-87, :92).  autograd runs three passes around the
+ * reference's layer (slice of the concat gradient made contiguous, leaky_relu_backward, correlation backward); this entry
+ * point reads the gradient where it lies and the activation's derivative off the SIGN of the stored forward output:
+ *   out_act  : what fn2_correlation_forward_fused wrote -- pointer at the first correlation channel of batch item 0 inside
+ *              the concat buffer, out_batch_stride elements between items (>= nOut*oH*oW)
+ *   grad_cat : gradient wrt the concat buffer, pointer at the same channel, grad_batch_stride elements between items
+ *   negative_slope > 0 (LeakyReLU; 1 = no activation): d/dx = 1 where out_act > 0, negative_slope elsewhere -- no mask
+ *              tensor, no copy of the pre-activation values
+ *   workspace: fn2_correlation_backward_fused_workspace_bytes(...) bytes of device scratch (the masked, contiguous
+ *              gradient the backward kernels read: ONE streaming pass instead of autograd's two; overwritten)
+ *   grad_in1, grad_in2 : B x C x H x W, fully written; bit-identical to the unfused composition on the same kernels. */
+size_t fn2_correlation_backward_fused_workspace_bytes(int dtype, int B, int H, int W, int pad_size, int kernel_size,
+                                                      int max_displacement, int stride1, int stride2);
+int fn2_correlation_backward_fused(const void *in1, const void *in2, const void *out_act, int64_t out_batch_stride,
+                                   const void *grad_cat, int64_t grad_batch_stride, float negative_slope,
+                                   void *workspace, size_t workspace_bytes, void *grad_in1, void *grad_in2,
+                                   int dtype, int B, int C, int H, int W,
+                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                   int algo, void *stream);
+
 /* Replaces resample2d_kernel_forward (resample2d_kernel.cuh:5-10; kernel
  * resample2d_kernel.cu:15-72).  float32 only, like the reference.
  *   img  : B x C x Hi x Wi with element strides img_strides[4] (NULL = contiguous); the

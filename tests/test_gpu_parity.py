@@ -1161,6 +1161,7 @@ def test_correlation_backward_on_real_training_gradient(dev):
     import fn2_capi
     from harness.train import Trainer, synthetic_batch
     tr = Trainer(dev)
+    tr.model.fused_training = False          # the separate Correlation module, whose gradOutput is what this test captures
     cap = {}
     inner = tr.model.corr.forward
 
@@ -1438,3 +1439,45 @@ def test_correlation_f16x2_huge_and_tiny_operands(dev):
     f1, f2 = _corr_bwd_fp64(m1.to(dev), m2.to(dev), go)
     g1, g2 = fn2_capi.correlation_backward(a, b, go, 20, 1, 20, 1, 2)
     assert _rel(torch.ldexp(g1.double(), torch.tensor(100)), f1) <= 2e-6 and _rel(torch.ldexp(g2.double(), torch.tensor(-100)), f2) <= 2e-6
+
+
+def test_correlation_leakyrelu_cat_backward(dev, oracle):
+    """N1, training half: the differentiable fused op against the three statements of FlowNetC.py:86-92 under autograd -- same
+    concat buffer, BIT-identical gradients for both feature maps and the redirected features (the masked gradient is the same
+    fp32 product s * g, the backward kernels are the same) -- and against the oracle on the masked gradient."""
+    import fn2_capi
+    from networks.correlation_package.correlation import Correlation, CorrelationLeakyReLUCat
+    for (B, C, H, W, Cr) in ((2, 64, 16, 24, 8), (1, 256, 48, 64, 32), (2, 64, 56, 72, 32)):
+        g = torch.Generator().manual_seed(B * 1000 + W)
+        a0 = torch.randn(B, C, H, W, generator=g)
+        b0 = torch.randn(B, C, H, W, generator=g)
+        r0 = torch.randn(B, Cr, H, W, generator=g)
+        gbuf = torch.randn(B, Cr + 441, H, W, generator=g).to(dev)
+        leaves = lambda: [t.to(dev).requires_grad_() for t in (a0, b0, r0)]
+        a, b, r = leaves()
+        fused = CorrelationLeakyReLUCat(20, 1, 20, 1, 2, negative_slope=0.1)(a, b, r)
+        fused.backward(gbuf)
+        a2, b2, r2 = leaves()
+        plain = torch.cat((r2, torch.nn.functional.leaky_relu(Correlation(20, 1, 20, 1, 2, 1)(a2, b2), 0.1)), 1)
+        plain.backward(gbuf)
+        assert torch.equal(fused, plain)
+        assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad) and torch.equal(r.grad, r2.grad), (B, C, H, W)
+        # the C ABI entry point directly (ctypes), and the oracle on the masked gradient
+        g1, g2 = fn2_capi.correlation_backward_fused(a.detach(), b.detach(), fused.detach(), gbuf, Cr, 0.1, 20, 1, 20, 1, 2)
+        assert torch.equal(g1, a.grad) and torch.equal(g2, b.grad)
+        if C * H * W <= 64 * 16 * 24 * 4:
+            out = fused.detach()[:, Cr:].cpu().numpy()
+            gm = gbuf[:, Cr:].cpu().numpy()
+            gm = np.where(out > 0, gm, gm * np.float32(0.1)).astype(np.float32)
+            o1, o2 = oracle.corr_bwd(a0.numpy(), b0.numpy(), np.ascontiguousarray(gm), 20, 1, 20, 1, 2)
+            assert max_abs(g1.cpu().numpy(), o1) <= TOL and max_abs(g2.cpu().numpy(), o2) <= TOL
+    # rejected: a slope that does not keep the sign, a workspace that is too small
+    import ctypes
+    lib = fn2_capi.lib()
+    a, b = a.detach(), b.detach()
+    ws = torch.empty(16, device=dev)
+    args = lambda slope, w, wb: (fn2_capi._p(a), fn2_capi._p(b), fn2_capi._p(fused), ctypes.c_int64(fused.shape[1] * H * W), fn2_capi._p(gbuf),
+                                 ctypes.c_int64(fused.shape[1] * H * W), ctypes.c_float(slope), fn2_capi._p(w), ctypes.c_size_t(wb), fn2_capi._p(g1), fn2_capi._p(g2),
+                                 0, B, C, H, W, 20, 1, 20, 1, 2, 0, None)
+    assert lib.fn2_correlation_backward_fused(*args(0.0, ws, 64)) == -1 and lib.fn2_correlation_backward_fused(*args(-0.1, ws, 64)) == -1
+    assert lib.fn2_correlation_backward_fused(*args(0.1, ws, 64)) == -1
