@@ -181,11 +181,14 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     // waves scale the G operand).  Written by staging wave 0 before the last barrier of the previous task / barrier (A), read by
     // the matrix waves after it.
     __shared__ int scl_k[2];
-    // ... and, since round 4, ONE EXPONENT PER CHANNEL for the X operand: kx[task parity][channel of the task].  X is the A matrix of
+    // ... and, since round 4, ONE EXPONENT PER CHANNEL for the X operand: scl_sx[task parity][channel of the task].  X is the A matrix of
     // the products (rows = channels): a per-row scale leaves through the rows of D, i.e. per gradient channel, exactly.  With one
     // exponent per task, channels 1000 x smaller than the task's typical magnitude kept 13 bits (their residual term went
     // f16-subnormal): tests/test_gpu_parity.py::test_correlation_backward_per_channel_error.  scl_k[0] is unused now.
-    __shared__ int scl_kx[2][CG];
+    // The float scales 2^kx, ordered for the staging lanes: position 8 (c & 7) + (c >> 3), so that the eight channels a lane stages
+    // (c = s_ch + 8 i) are 32 contiguous bytes -- two 16-byte reads at the top of a phase instead of a read and a wait per item;
+    // the epilogue takes a channel's exponent out of the same word
+    __shared__ __attribute__((aligned(16))) float scl_sx[2][CG];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,11 +218,22 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     struct Task { int flip, n, py, rg, cg; };
     auto get_task = [&](int t) -> Task {
         Task k;
+        // Task order: channel group fastest, then row group, then the GRADIENT, then (y parity, batch item): the 48 tasks that read
+        // the gO planes of one (n, py) -- both gradients, every row group and channel group -- are consecutive, i.e. run on ONE XCD
+        // (xcd_remap keeps consecutive tasks together) within two of its three rounds, and share its L2.  With the gradient as the
+        // outermost index (rounds 2-3) the two gradients of an item ran 384 tasks apart and each fetched gO from the fabric again.
         k.cg = t % p.NCGR; t /= p.NCGR;
         k.rg = t % p.NRG; t /= p.NRG;
+#ifdef FN2_ABL_FLIPOUTER   // A/B: the round-3 order
         k.py = t & 1; t >>= 1;
         k.n = t % p.B;
         k.flip = p.nflip == 2 ? t / p.B : p.flip0;
+#else
+        k.flip = p.nflip == 2 ? t % 2 : p.flip0;
+        if (p.nflip == 2) t >>= 1;
+        k.py = t & 1; t >>= 1;
+        k.n = t;
+#endif
         k.cg = __builtin_amdgcn_readfirstlane(k.cg); k.rg = __builtin_amdgcn_readfirstlane(k.rg);
         k.py = __builtin_amdgcn_readfirstlane(k.py); k.n = __builtin_amdgcn_readfirstlane(k.n);
         k.flip = __builtin_amdgcn_readfirstlane(k.flip);
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     // row ai = g, wave w owns channels w, w + NWAVES, ... (scalars): the LDS offset is a lane part + 1 KB per channel, the global
     // row a buffer store with one lane offset and a scalar channel offset.
     // ksum = kx + kg: the matrix-core sums carry 2^ksum (the operand scales of the task); removed with the 1/C, exactly
-    auto store_rows = [&](const Task &tk, int kg, int par) {   // kg: the task's G exponent; par: which half of scl_kx holds its X exponents
+    auto store_rows = [&](const Task &tk, int kg, int par) {   // kg: the task's G exponent; par: which half of scl_sx holds its X exponents
         int ln = lane;
         asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
         const int g = ln >> 4, xg = 4 * (ln & 15);
@@ -256,7 +270,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         float f = 1.0f;
         if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
         const int kx_ex = -lgC;   // sums of the fp32 fallback (the matrix-core sums of channel c also carry 2^(kx[c] + kg))
-        auto ksum_of = [&](int c) { return to_sgpr(scl_kx[par][c & (CG - 1)]) + kg; };
+        auto ksum_of = [&](int c) {
+            const int cc = c & (CG - 1);
+            const int bits = to_sgpr(__builtin_bit_cast(int, scl_sx[par][8 * (cc & 7) + (cc >> 3)]));
+            return (bits >> 23) - 127 + kg;
+        };
         auto scaled = [&](f4 val, int kx) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = __builtin_ldexpf(val[e], kx);
@@ -415,13 +433,18 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             kg = scale_exp(wave_sum(tg));
         };
         auto publish = [&](int par, int kx, int kg) {
-            if (wave == 0) { scl_kx[par][lane] = kx; if (lane == 0) scl_k[1] = kg; }
+            if (wave == 0) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));   // (the table address is formed here, not kept across the task loop: it would be spilled)
+                scl_sx[par][8 * (ln & 7) + (ln >> 3)] = f16s::scale_from_exp(kx);
+                if (ln == 0) scl_k[1] = kg;
+            }
         };
         XSet XA0, XA1, XB0, XB1;
         int t = (int)xcd_remap(blockIdx.x, gridDim.x);
         Samp SM;
         int kx_n = 0, kg_n = 0;                                // the next task's scale exponents (kx: of this lane's sample channel)
-        int it = 0;                                            // tasks done by this workgroup: parity selects the half of scl_kx
+        int it = 0;                                            // tasks done by this workgroup: parity selects the half of scl_sx
         if (t < ntasks) {
             const Task tk = get_task(t);
             sample_issue(tk, SM);
@@ -442,16 +465,22 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const Task tn = get_task(has_next ? t + (int)gridDim.x : t);
             const bool first = t < (int)gridDim.x;
             const int kg_cur = kg_n, par = it & 1;
-            auto sxf = [&](int ch, int k) { return f16s::scale_from_exp(scl_kx[par][ch * CK + 2 * NSW * k + s_ch]); };
             auto one_u = [&](int u, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
+                // the scale of item k of chunk ch (channel s_ch + 8 (k + 4 ch)) is read from the table one item ahead of its use: all
+                // eight of them in registers across the phase do not fit the staging waves' budget (168 with four X sets in flight)
+                const float *sxp = &scl_sx[par][8 * s_ch];
                 // phase 1 (the matrix waves gather the G operands of u): request the next X chunks, write both X chunks of u
                 // (all loads first: interleaving them with the items of x_write measured 4 us slower)
+                float sc = sxp[0];
                 if (u + 1 < NU) { x_issue(N0, tk, u + 1, 0); x_issue(N1, tk, u + 1, 1); }
                 else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
 #pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, k, sxf(0, k));
-#pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, k, sxf(1, k));
+                for (int k = 0; k < 2 * XK; ++k) {
+                    const float nx = sxp[k + 1 < 2 * XK ? k + 1 : k];
+                    if (k < XK) x_write1(C0, smem + X_OFS, k, sc);
+                    else x_write1(C1, smem + X_OFS + XBUF, k - XK, sc);
+                    sc = nx;
+                }
                 if (first && u < 2) stamp(4 + 4 * u);
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 if (first && u < 2) stamp(5 + 4 * u);
@@ -490,7 +519,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
 
-    int itm = 0;   // tasks done by this workgroup (parity: which half of scl_kx holds the current task's X exponents)
+    int itm = 0;   // tasks done by this workgroup (parity: which half of scl_sx holds the current task's X exponents)
     auto run_task = [&](const Task &tk, auto flipc, bool first) {
         constexpr int FLIP = decltype(flipc)::value;
         const int kg_cur = to_sgpr(scl_k[1]);                   // published before the barrier this wave just passed

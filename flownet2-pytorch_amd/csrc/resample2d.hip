@@ -485,6 +485,211 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
     }
 }
 
+// Forward, 4 ADJACENT pixels per thread: the flow arrives as two 16-byte loads and every output plane leaves as one 16-byte store per
+// thread (resample_fwd_tiled: 4-byte accesses strided by the workgroup size -- four times the vector-memory instructions for the
+// same bytes, and the CU's vector-memory path retires instructions, not bytes: ~33 cycles each inside a kernel).
+// TH x 64 tile, TH * 16 threads; window double-buffered per channel as in resample_fwd_tiled.
+template <int TH, int R>
+__global__ __launch_bounds__(TH * 16, (2 * TH * 16 + 255) / 256) void resample_fwd_tiled4(const float *__restrict__ img, ImgStrides is,
+                                                                                        const float *__restrict__ flow, float *__restrict__ out,
+                                                                                        int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
+                                                                                        int bilinear)
+{
+    constexpr int TW = 64, NT = TH * 16, WH = TH + 2 * R, WW = TW + 2 * R, NW = (WH * (WW / 4) + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float win[2][WH * WW];
+    enum { IN_WIN = 2, DX = 4, DY = 8 };
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const long HW = (long)H * W;
+    const int x0 = X0 + 4 * (tid & 15), y = Y0 + (tid >> 4);
+    const bool live = x0 < W && y < H;                        // W % 4 == 0: a group is entirely inside or outside
+    const long p0 = live ? (long)y * W + x0 : 0;
+    const f4 vdx = *reinterpret_cast<const f4 *>(flow + (long)b * 2 * HW + p0);
+    const f4 vdy = *reinterpret_cast<const f4 *>(flow + (long)b * 2 * HW + HW + p0);
+    f4 wreg[NW];
+    auto win_load = [&](const float *I) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int i = tid + NT * j;
+            asm volatile("" : "+v"(i));
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                v = *reinterpret_cast<const f4 *>(I + (long)gy * is.h + gx);
+            wreg[j] = v;
+        }
+    };
+    auto win_write = [&](float *dst) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(dst + 4 * i) = wreg[j];
+        }
+    };
+    if (C > 0) win_load(img + (long)b * is.b);
+    float alpha[4], beta[4];
+    int base[4], flags[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xf = (float)(x0 + k) + vdx[k], yf = (float)y + vdy[k];
+        int xL, xR, yT, yB;
+        alpha[k] = beta[k] = 0.0f;
+        if (bilinear) {
+            const float fx = floorf(xf), fy = floorf(yf);
+            alpha[k] = xf - fx; beta[k] = yf - fy;                     // (:45-46)
+            xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1);     // clamped with the OUTPUT dims (:49-52)
+            xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
+            yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1);
+            yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
+        } else {
+            xL = xR = clampi(clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), 0, Wi - 1);   // (:66-67)
+            yT = yB = clampi(clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1), 0, Hi - 1);
+        }
+        const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+        const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+        base[k] = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
+        flags[k] = (in ? IN_WIN : 0) | (xR != xL ? DX : 0) | (yB != yT ? DY : 0);
+    }
+    if (C > 0) win_write(win[0]);
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        const float *I = img + (long)b * is.b + (long)c * is.c;
+        const float *wc = win[c & 1];
+        if (c + 1 < C) win_load(I + is.c);
+        f4 res;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int fl = flags[k], o = base[k];
+            asm volatile("" : "+v"(fl), "+v"(o));
+            float i00, i01, i10, i11;
+            if (fl & IN_WIN) {
+                const int ox = (fl & DX) ? 1 : 0, oy = (fl & DY) ? WW : 0;
+                i00 = wc[o]; i01 = wc[o + ox]; i10 = wc[o + oy]; i11 = wc[o + oy + ox];
+            } else {
+                const int ox = (fl & DX) ? (int)is.w : 0, oy = (fl & DY) ? (int)is.h : 0;
+                i00 = I[o]; i01 = I[o + ox]; i10 = I[o + oy]; i11 = I[o + oy + ox];
+            }
+            float val;
+            if (bilinear) {
+                const double a = (double)alpha[k], be = (double)beta[k];   // "1." literals -> double (:56-59)
+                val = 0.0f;
+                val = val + (float)(((1. - a) * (1. - be)) * (double)i00);
+                val = val + (float)((a * (1. - be)) * (double)i01);
+                val = val + (float)(((1. - a) * be) * (double)i10);
+                val = val + (float)((a * be) * (double)i11);
+            } else {
+                val = i00;
+            }
+            res[k] = val;
+        }
+        if (live) store_out(reinterpret_cast<f4 *>(out + ((long)b * C + c) * HW + p0), res);
+        if (c + 1 < C) win_write(win[(c + 1) & 1]);
+        __syncthreads();
+    }
+}
+
+// Forward with ALL image channels of the window resident in LDS (C == NC, typically 3): one workgroup per CU owns a TH x TW tile,
+// loads the NC windows at once (one barrier in the whole kernel instead of one per channel), forms the corner offsets and the
+// double-precision weights once per pixel and gathers the NC channels back to back.
+template <int TH, int TW, int R, int NC>
+__global__ __launch_bounds__(1024, 4) void resample_fwd_tiled_all(const float *__restrict__ img, ImgStrides is,
+                                                                const float *__restrict__ flow, float *__restrict__ out,
+                                                                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int bilinear)
+{
+    constexpr int NT = 1024, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float win[NC][WH * WW];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const long HW = (long)H * W;
+    // the flow of the thread's pixels and every window group: all requested before anything is used
+    float fdx[PPT], fdy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        const long p = (x < W && y < H) ? (long)y * W + x : 0;
+        fdx[k] = flow[(long)b * 2 * HW + p]; fdy[k] = flow[(long)b * 2 * HW + HW + p];
+    }
+    f4 wreg[NC][NW];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
+            wreg[c][j] = v;
+        }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(&win[c][4 * i]) = wreg[c][j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        if (!((x < W) && (y < H))) continue;
+        const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
+        int xL, xR, yT, yB;
+        float alpha = 0.0f, beta = 0.0f;
+        if (bilinear) {
+            const float fx = floorf(xf), fy = floorf(yf);
+            alpha = xf - fx; beta = yf - fy;                           // (:45-46)
+            xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1);     // clamped with the OUTPUT dims (:49-52)
+            xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
+            yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1);
+            yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
+        } else {
+            xL = xR = clampi(clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), 0, Wi - 1);   // (:66-67)
+            yT = yB = clampi(clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1), 0, Hi - 1);
+        }
+        const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+        const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+        const double a = (double)alpha, be = (double)beta;             // "1." literals -> double (:56-59)
+        const double w00 = (1. - a) * (1. - be), w01 = a * (1. - be), w10 = (1. - a) * be, w11 = a * be;
+        const int o = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
+        const int ox = (xR != xL) ? (in ? 1 : (int)is.w) : 0, oy = (yB != yT) ? (in ? WW : (int)is.h) : 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float i00, i01, i10, i11;
+            if (in) {
+                const float *wc = win[c];
+                i00 = wc[o]; i01 = wc[o + ox]; i10 = wc[o + oy]; i11 = wc[o + oy + ox];
+            } else {
+                const float *I = img + (long)b * is.b + (long)c * is.c;
+                i00 = I[o]; i01 = I[o + ox]; i10 = I[o + oy]; i11 = I[o + oy + ox];
+            }
+            float val;
+            if (bilinear) {
+                val = 0.0f;
+                val = val + (float)(w00 * (double)i00);
+                val = val + (float)(w01 * (double)i01);
+                val = val + (float)(w10 * (double)i10);
+                val = val + (float)(w11 * (double)i11);
+            } else {
+                val = i00;
+            }
+            store_out(out + ((long)b * NC + c) * HW + (y * W + x), val);
+        }
+    }
+}
+
 template <int TH, int TW, int R, int NT, int WPE, int ACC = 0>
 __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
                                                             const float *__restrict__ flow,
@@ -792,6 +997,24 @@ static int resample2d_forward_impl(const float *img, const int64_t *img_strides,
         hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024), \
                            0, s, img, is, flow, out, C, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);       \
     } while (0)
+        if (((bilinear >> 14) & 3) == 1 && aligned(flow, 16) && aligned(out, 16)) {   // profiling: 4 adjacent pixels per thread, 48 x 64 tiles
+            const int tiles_y = (H + 47) / 48;
+            hipLaunchKernelGGL((resample_fwd_tiled4<48, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(768), 0, s,
+                               img, is, flow, out, C, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);
+            return launch_status();
+        }
+        if (((bilinear >> 14) & 3) == 2 && aligned(flow, 16) && aligned(out, 16)) {   // ... 64 x 64 tiles, 1024 threads
+            const int tiles_y = (H + 63) / 64;
+            hipLaunchKernelGGL((resample_fwd_tiled4<64, 16>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024), 0, s,
+                               img, is, flow, out, C, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);
+            return launch_status();
+        }
+        if (((bilinear >> 12) & 3) == 3 && C == 3) {   // profiling: every channel window resident, 96 x 64 tiles, one workgroup per CU
+            const int tiles_y = (H + 95) / 96;
+            hipLaunchKernelGGL((resample_fwd_tiled_all<96, TW, 16, 3>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024), 0, s,
+                               img, is, flow, out, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);
+            return launch_status();
+        }
         const int th = (bilinear >> 12) & 3 ? ((bilinear >> 12) & 3) == 1 ? 48 : 32 : tile_height(B, H, tiles_x);
         if (th == 48) FN2_RF(48); else FN2_RF(32);
 #undef FN2_RF
@@ -875,7 +1098,10 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
         case 6: FN2_RB(96, 16, 4, 0); break;
         case 7: FN2_RB(96, 16, 4, 1); break;
         case 9: FN2_RB(48, 16, 4, 0); break;
-        default: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48, 16, 8, 0); else FN2_RB(32, 16, 8, 0); break;
+        case 10: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48, 16, 8, 0); else FN2_RB(32, 16, 8, 0); break;   // the round-3 choice
+        // 32-row tiles with fp64 cells (74 KB of LDS: two workgroups per CU): measured fastest on both test flows -- 8 x 3 x 384 x 512,
+        // white-noise flow 53.8 us against 57.2-59.8 us for 48 x 64 fp32 cells in one round of workgroups, smooth flow 38.4 against 44.5
+        default: FN2_RB(32, 16, 8, 1); break;
         }
 #undef FN2_RB
     } else {

@@ -28,11 +28,14 @@ def timeit(fn, n=20):
     return ts[len(ts) // 2]
 for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth)):
     print(name)
-    for flags, lab in ((1, "fwd tiled"), (1 | 0x1000, "fwd tiled 48x64"), (1 | 0x2000, "fwd tiled 32x64"), (1 | 0x100, "fwd untiled")):
+    for flags, lab in ((1, "fwd tiled"), (1 | 0x1000, "fwd tiled 48x64"), (1 | 0x2000, "fwd tiled 32x64"), (1 | 0x3000, "fwd 96x64, 3 windows resident"), (1 | 0x4000, "fwd 48x64, 4 px per thread"), (1 | 0x8000, "fwd 64x64, 4 px per thread"), (1 | 0x100, "fwd untiled")):
         t = timeit(lambda: lib.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
-        print("   %-28s %.1f us" % (lab, t))
+        torch.cuda.synchronize()
+        if flags == 1:
+            ref_out = out.clone()
+        print("   %-28s %.1f us   max |d| vs the first row %.2e" % (lab, t, float((out - ref_out).abs().max())))
     ref = None
-    for flags, lab in ((1, "bwd tiled"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"),
+    for flags, lab in ((1, "bwd tiled (default)"), (1 | 0xA000, "bwd tiled, round-3 choice"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"),
                        (1 | 0x5000, "bwd 48x64 +-12 f32 CAS"), (1 | 0x4000, "bwd 48x64 +-12 fp64 cells"), (1 | 0x8000, "bwd 32x64 +-16 fp64 cells"),
                        (1 | 0xC000, "bwd 48x64 +-16 fp64, 1 WG/CU"), (1 | 0x9000, "bwd 48x64 +-16 f32, 1 WG/CU"),
                        (1 | 0x6000, "bwd 96x64 +-16 f32, 1 WG/CU"), (1 | 0x7000, "bwd 96x64 +-16 fp64, 1 WG/CU"),
