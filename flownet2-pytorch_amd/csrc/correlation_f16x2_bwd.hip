@@ -171,6 +171,15 @@ constexpr int NSW = 4, NWAVES = NSW + 8;   // staging waves, waves per workgroup
 constexpr int XK = 32 / (2 * NSW);          // X items per chunk (32 channels) and staging lane
 struct XSet { u4 v[XK][2]; };      // one X chunk of one lane: [slot][half] x 16 B (8 pixels)
 
+// The lane id, formed where it is needed (two instructions) instead of an opaque copy of a variable that lives -- and may be
+// spilled -- across the task loop (correlation_f16x2_bwd_wide.hip)
+__device__ __forceinline__ int lane_now()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // VAR: profiling switches (0 = the real kernel): 1 no MFMA, 2 no global loads, 4 no stores, 8 no gathers / operand reads,
 //      16 no split / LDS staging writes
 template <int VAR>
@@ -247,8 +256,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
     // row a buffer store with one lane offset and a scalar channel offset.
     // ksum = kx + kg: the matrix-core sums carry 2^ksum (the operand scales of the task); removed with the 1/C, exactly
     auto store_rows = [&](const Task &tk, int kg, int par) {   // kg: the task's G exponent; par: which half of scl_sx holds its X exponents
-        int ln = lane;
-        asm volatile("" : "+v"(ln));   // keeps the row geometry from being hoisted out of the task loop (and spilled)
+        int ln = lane_now();   // keeps the row geometry from being hoisted out of the task loop (and spilled)
         const int g = ln >> 4, xg = 4 * (ln & 15);
         constexpr int NRI = (CG + NWAVES - 1) / NWAVES;      // channels per wave (the last one partial)
         const int y = 2 * (4 * tk.rg + g) + tk.py;
@@ -338,8 +346,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         auto g_dma = [&](const Task &tk, int u) {
             if (VAR & 2) return;
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
+            int ln = lane_now();
             const int bi = ln >> 4, pc = ln & 15;
 #pragma unroll
             for (int k = 0; k < 4 / NSW; ++k) {
@@ -400,8 +407,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         constexpr int U0 = 2;
         struct Samp { u2 x, x2, g; };   // X: lane = channel of the task, 4 values of it (two rows, two places); G: as before
         auto sample_issue = [&](const Task &tk, Samp &S) {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
+            int ln = lane_now();
             const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
             const int ai = ln & 3, bi = (ln >> 2) & 3, q = ln >> 4;
@@ -434,8 +440,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         };
         auto publish = [&](int par, int kx, int kg) {
             if (wave == 0) {
-                int ln = lane;
-                asm volatile("" : "+v"(ln));   // (the table address is formed here, not kept across the task loop: it would be spilled)
+                int ln = lane_now();   // (the table address is formed here, not kept across the task loop: it would be spilled)
                 scl_sx[par][8 * (ln & 7) + (ln >> 3)] = f16s::scale_from_exp(kx);
                 if (ln == 0) scl_k[1] = kg;
             }
@@ -524,8 +529,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
         constexpr int FLIP = decltype(flipc)::value;
         const int kg_cur = to_sgpr(scl_k[1]);                   // published before the barrier this wave just passed
         const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(kg_cur);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        int ln = lane_now();
         const int f_i = ln & 15, f_g = ln >> 4;                 // pixel / channel index, k group
         const int f_ai = f_i >> 2, f_aj = f_i & 3;
         // X operand base: lane = (channel i, k group g): block 2j + (g&1), rows 2(g>>1), 2(g>>1)+1 -> the 16-byte unit 4j + g
@@ -552,8 +556,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             constexpr int XP = decltype(xp_c)::value;          // the wave's x parity, as a constant: part of the read's immediate offset
             typedef GL<FLIP> L;
             constexpr int SB = L::TI - 8;                                         // FLIP 1: one column less = one displacement row more
-            int l2 = lane;
-            asm volatile("" : "+v"(l2));
+            int l2 = lane_now();
             const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = (l2 >> 4) & 1, gg = l2 >> 5;
             const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * SB + 32 * blk + 4 * XP
                                    : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 8 * aj;

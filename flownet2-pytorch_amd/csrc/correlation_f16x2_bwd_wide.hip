@@ -118,10 +118,22 @@ constexpr int NSW = 4, NWAVES = NSW + 8;   // staging waves, waves per workgroup
 constexpr int XK = 32 / (2 * NSW);          // X items per chunk (32 channels) and staging lane
 struct XSet { u4 v[XK][2]; };
 
+// The lane id, formed where it is needed (two instructions).  An opaque copy of a `lane` variable kept across the task loop is what
+// this kernel used until round 4; once the register budget tipped, that variable was spilled and every gather began with a
+// scratch reload and a vmcnt(0) wait (+18 % on the kernel).
+__device__ __forceinline__ int lane_now()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    __shared__ int scl_k[2];   // scale exponents of the task about to start: [0] = kx + kg, [1] = kg (see the narrow kernel)
+    __shared__ int scl_k[2];   // [1] = kg, the G exponent of the task about to start (see the narrow kernel; [0] unused since round 4)
+    // one X scale per CHANNEL of the task (correlation_f16x2_bwd.hip): floats 2^kx at position 8 (c & 7) + (c >> 3), two task parities
+    __shared__ __attribute__((aligned(16))) float scl_sx[2][CG];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,9 +168,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
 
     // ---- write-out of the epilogue image (all waves): 256 rows (channel, centre row) of 64 floats, 4 rows per instruction
     float *Es = reinterpret_cast<float *>(smem + X_OFS);
-    auto store_rows = [&](const Task &tk, int ksum) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+    auto store_rows = [&](const Task &tk, int kg, int par) {
+        int ln = lane_now();
         const int g = ln >> 4, xg = 4 * (ln & 15), xw = WPX * tk.xw + xg;
         constexpr int NRI = (CG + NWAVES - 1) / NWAVES;
         const int y = 2 * (4 * tk.rg + g) + tk.py;
@@ -174,7 +185,12 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         for (int i = 0; i < NRI; ++i) vals[i] = read_row(chan(i) & (CG - 1));
         float f = 1.0f;
         if (!pow2) asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "s"(p.fC));
-        const int kx_mm = -ksum - lgC, kx_ex = -lgC;   // matrix-core sums / sums of the fp32 fallback
+        const int kx_ex = -lgC;   // sums of the fp32 fallback (the matrix-core sums of channel c also carry 2^(kx[c] + kg))
+        auto ksum_of = [&](int c) {
+            const int cc = c & (CG - 1);
+            const int bits = to_sgpr(__builtin_bit_cast(int, scl_sx[par][8 * (cc & 7) + (cc >> 3)]));
+            return (bits >> 23) - 127 + kg;
+        };
         auto scaled = [&](f4 val, int kx) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = __builtin_ldexpf(val[e], kx);
@@ -189,13 +205,14 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
             if (lane_ok && (__builtin_amdgcn_classf(vals[i][0], 0x207) | __builtin_amdgcn_classf(vals[i][1], 0x207) |
                             __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], kx_mm)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 2);   // sc1: see correlation_f16x2_bwd.hip
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, scaled(vals[i], -ksum_of(c) - lgC)), rso, (int)vo, (int)((tk.cg * CG + c) * HW * 4), 2);   // sc1: see correlation_f16x2_bwd.hip
         }
         if (bad) {   // an operand beyond the f16 range: those outputs again, as fp32 fma chains
 #pragma unroll 1
             for (int i = 0; i < NRI; ++i) {
                 if (!(bad >> i & 1)) continue;
                 const int c = chan(i);
+                const int ksum = ksum_of(c);
                 f4 val = read_row(c);
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
@@ -215,8 +232,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         // this lane's X chunk position: rebuilt from an opaque copy of the lane id wherever it is needed (kept in registers across
         // the task loop it is spilled, and a scratch reload waits for vmcnt(0) -- for the X loads just requested)
         auto x_ofs = [&]() {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
+            int ln = lane_now();
             const int piece = (ln & 3) + 4 * ((ln >> 4) & 1), row = (ln >> 2) & 3, chn = 2 * w8 + (ln >> 5);
             return chn * CHS + (piece >> 1) * 64 + (piece & 1) * 16 + (row >> 1) * 32 + (row & 1) * 8;
         };
@@ -228,8 +244,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         auto g_dma = [&](const Task &tk, int v) {
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
             const int u = v >= NU ? v - NU : v;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
+            int ln = lane_now();
             const int bi = ln >> 4, pc = ln & 15;
             const int ai = w8;
             const int tj = tk.flip ? 20 - 4 * u - bi + ai : 4 * u + bi - ai;
@@ -246,8 +261,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         auto x_issue = [&](XSet &L, const Task &tk, int v, int ch) {
             const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
             const int u = v >= NU ? v - NU : v;
-            int ln = lane;   // the lane geometry is rebuilt here (opaque copy): four registers less across the task loop
-            asm volatile("" : "+v"(ln));
+            int ln = lane_now();   // the lane geometry is rebuilt here (opaque copy): four registers less across the task loop
             const int piece = (ln & 3) + 4 * ((ln >> 4) & 1), row = (ln >> 2) & 3, chn = 2 * w8 + (ln >> 5);
             const int il = 4 * tk.rg - DR + 4 * u + row;
             const int x = nbr_x0(tk, v) + 8 * piece;
@@ -260,9 +274,8 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
                 L.v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(vo + 16), soff, 0);
             }
         };
-        f16s::scale2_t sc_x = f16s::scale2_from_exp(0);
-        auto x_write1 = [&](const XSet &L, char *buf, int w_ofs, int k) {
-            const f4 x0 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][0]), sc_x), x1 = f16s::pk_scale4(__builtin_bit_cast(f4, L.v[k][1]), sc_x);
+        auto x_write1 = [&](const XSet &L, char *buf, int w_ofs, int k, float sc) {
+            const f4 x0 = __builtin_bit_cast(f4, L.v[k][0]) * sc, x1 = __builtin_bit_cast(f4, L.v[k][1]) * sc;   // power of two: exact
             char *dst = buf + w_ofs + k * 2 * NSW * CHS;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -278,33 +291,48 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         // operand sample of a task (f16x2_split.h), inside the centre window: X from the neighbour rows of u = 2, G from the gO
         // image of the same u
         constexpr int U0 = 2;
-        struct Samp { u2 x, g; };
+        struct Samp { u2 x, x2, g; };   // X: lane = channel of the task, 4 values of it; G: as before
         auto sample_issue = [&](const Task &tk, Samp &S) {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
+            int ln = lane_now();
             const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.nbr[tk.flip] + (long)tk.n * p.C * HW), 0, xbytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gout + (long)tk.n * D * D * HW), 0, gbytes, 0x00020000);
             const int ai = ln & 3, bi = (ln >> 2) & 3, q = ln >> 4;
             const int tj = tk.flip ? 20 - 4 * U0 - bi + ai : 4 * U0 + bi - ai;
             const int ilg = tk.flip ? 4 * tk.rg - DR + 4 * U0 + bi : 4 * tk.rg + ai;
-            const int x = WPX * tk.xw + 2 * (((5 * ln) >> 1) & 31);
+            // sample columns inside the part of the window that lies in the image (the last window of a row may be narrower than 64 px,
+            // but never narrower than 8: a sample taken beyond the row reads zeros and would leave the channel unscaled)
+            const int xs = 2 * (((5 * ln) >> 1) & 31), xs2 = (xs + 32) & 63;
+            const int x = WPX * tk.xw + (WPX * tk.xw + xs < p.W ? xs : xs & 7);
             const int c = tk.cg * CG + ln, ilx = 4 * tk.rg - DR + 4 * U0 + (ln & 3);
             const int ti = (5 * q + (ln & 3) + bi) % D;
             const unsigned ox = (ilx >= 0 && ilx < HL && x < p.W) ? (unsigned)((c * HW + (long)(2 * ilx + tk.py) * p.W + x) * 4) : 0x80000000u;
+            const int ilx2 = 4 * tk.rg - DR + 4 * U0 + ((ln + 2) & 3), xb = WPX * tk.xw + (WPX * tk.xw + xs2 < p.W ? xs2 : xs2 & 7);
+            const unsigned ox2 = (ilx2 >= 0 && ilx2 < HL && xb < p.W) ? (unsigned)((c * HW + (long)(2 * ilx2 + tk.py) * p.W + xb) * 4) : 0x80000000u;
             const unsigned og = (ilg >= 0 && ilg < HL && x < p.W) ? (unsigned)((((tj * D + ti) * p.H + 2 * ilg + tk.py) * p.W + x) * 4) : 0x80000000u;
             S.x = __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox, 0, 0);
+            S.x2 = __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox2, 0, 0);
             S.g = __builtin_amdgcn_raw_buffer_load_b64(rsg, (int)og, 0, 0);
         };
-        auto sample_scales = [&](const Samp &S, int &kx, int &kg) {
-            const unsigned tx = exp_stat(S.x[0]) + exp_stat(S.x[1]), tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
-            kx = scale_exp(wave_sum(tx));
+        auto sample_scales = [&](const Samp &S, int &kx, int &kg) {   // kx: this lane's channel (largest of four samples in [1, 2))
+            const unsigned e0 = (S.x[0] >> 23) & 0xffu, e1 = (S.x[1] >> 23) & 0xffu, e2 = (S.x2[0] >> 23) & 0xffu, e3 = (S.x2[1] >> 23) & 0xffu;
+            const unsigned em = max(max(e0, e1), max(e2, e3));
+            const int k = 127 - (int)em;
+            kx = em == 0u ? 0 : (k < -126 ? -126 : k);
+            const unsigned tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
             kg = scale_exp(wave_sum(tg));
         };
-        auto publish = [&](int kx, int kg) { if (tid == 0) { scl_k[0] = kx + kg; scl_k[1] = kg; } };
+        auto publish = [&](int par, int kx, int kg) {
+            if (wave == 0) {
+                int ln = lane_now();
+                scl_sx[par][8 * (ln & 7) + (ln >> 3)] = f16s::scale_from_exp(kx);
+                if (ln == 0) scl_k[1] = kg;
+            }
+        };
         XSet XA0, XA1, XB0, XB1;
         int t = (int)xcd_remap(blockIdx.x, gridDim.x);
         Samp SM;
         int kx_n = 0, kg_n = 0;
+        int it = 0;
         if (t < ntasks) {
             const Task tk = get_task(t);
             sample_issue(tk, SM);
@@ -313,24 +341,29 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
             g_dma(tk, 0);
             dma_wait();
             sample_scales(SM, kx_n, kg_n);
-            publish(kx_n, kg_n);
+            publish(0, kx_n, kg_n);
         }
         __syncthreads();                                       // (A) G(0) complete, the first task's exponents published
         for (; t < ntasks; t += gridDim.x) {
             const Task tk = get_task(t);
             const bool has_next = t + (int)gridDim.x < ntasks;
             const Task tn = get_task(has_next ? t + (int)gridDim.x : t);
-            const int ksum = kx_n + kg_n;
-            sc_x = f16s::scale2_from_exp(kx_n);
+            const int kg_cur = kg_n, par = it & 1;
             auto one_v = [&](int v, XSet &C0, XSet &C1, XSet &N0, XSet &N1) {
                 // phase 1 (the matrix waves gather the G operands of v): request the next X chunks, write both X chunks of v
+                int l5 = lane_now();
+                const float *sxp = &scl_sx[par][8 * (2 * w8 + (l5 >> 5))];   // the scales of the lane's eight channels, read one item ahead
+                float sc = sxp[0];
                 if (v + 1 < tk.nv) { x_issue(N0, tk, v + 1, 0); x_issue(N1, tk, v + 1, 1); }
                 else if (has_next) { x_issue(N0, tn, 0, 0); x_issue(N1, tn, 0, 1); }
                 const int w_ofs = x_ofs();
 #pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C0, smem + X_OFS, w_ofs, k);
-#pragma unroll
-                for (int k = 0; k < XK; ++k) x_write1(C1, smem + X_OFS + XBUF, w_ofs, k);
+                for (int k = 0; k < 2 * XK; ++k) {
+                    const float nx = sxp[k + 1 < 2 * XK ? k + 1 : k];
+                    if (k < XK) x_write1(C0, smem + X_OFS, w_ofs, k, sc);
+                    else x_write1(C1, smem + X_OFS + XBUF, w_ofs, k - XK, sc);
+                    sc = nx;
+                }
                 __syncthreads();                               // (B) the G image is free, the X chunks complete
                 // phase 2 (all MFMAs of v): the next G image by DMA (and the next task's operand sample, ahead of it)
                 if (v + 1 < tk.nv) g_dma(tk, v + 1);
@@ -342,10 +375,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
                 one_v(v, XA0, XA1, XB0, XB1);
                 one_v(v + 1, XB0, XB1, XA0, XA1);
             }
-            if (has_next) { sample_scales(SM, kx_n, kg_n); publish(kx_n, kg_n); }
+            if (has_next) { sample_scales(SM, kx_n, kg_n); publish(par ^ 1, kx_n, kg_n); }
             __syncthreads();                                   // epilogue image (over the X buffers) complete
-            store_rows(tk, ksum);
+            store_rows(tk, kg_cur, par);
             __syncthreads();                                   // image read: the X buffers are free for the next task
+            ++it;
         }
         return;
     }
@@ -354,12 +388,12 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
     const int xpar = w8 & 1;
     const int role = __builtin_amdgcn_readfirstlane(w8 >> 1);
 
+    int itm = 0;   // tasks done by this workgroup: parity selects the half of scl_sx
     auto run_task = [&](const Task &tk, auto flipc) {
         constexpr int FLIP = decltype(flipc)::value;
-        const int ksum = to_sgpr(scl_k[0]);
-        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(to_sgpr(scl_k[1]));
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        const int kg_cur = to_sgpr(scl_k[1]);
+        const f16s::scale2_t sc_g2 = f16s::scale2_from_exp(kg_cur);
+        int ln = lane_now();
         const int f_i = ln & 15, f_g = ln >> 4;
         const int f_ai = f_i >> 2, f_aj = f_i & 3;
         const int xb = xpar * PARS + f_i * CHS + f_g * 16;
@@ -378,8 +412,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
             constexpr int XP = decltype(xp_c)::value;
             typedef GL<FLIP> L;
             constexpr int SB = L::TI - 8;
-            int l2 = lane;
-            asm volatile("" : "+v"(l2));
+            int l2 = lane_now();
             const int ai = (l2 & 15) >> 2, aj = l2 & 3, blk = (l2 >> 4) & 1, gg = l2 >> 5;
             const int lbase = FLIP ? ai * L::AI + 2 * gg * L::BI + (DR - 4 * blk + aj) * L::TI - 3 * SB + 32 * blk + 4 * XP
                                    : ai * L::AI + 2 * gg * L::BI + (DR + 4 * blk - aj) * L::TI + 8 * aj;
@@ -514,11 +547,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
         default: scatter(std::integral_constant<int, 3>{}); break;
         }
         __syncthreads();
-        store_rows(tk, ksum);
+        store_rows(tk, kg_cur, itm & 1);
         __syncthreads();
     };
     __syncthreads();                                           // (A) G(0) of the first task complete, its scale exponents published
-    for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x) {
+    for (int t = (int)xcd_remap(blockIdx.x, gridDim.x); t < ntasks; t += gridDim.x, ++itm) {
         const Task tk = get_task(t);
         if (tk.flip) run_task(tk, std::integral_constant<int, 1>{});
         else run_task(tk, std::integral_constant<int, 0>{});

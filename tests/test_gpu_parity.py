@@ -1368,14 +1368,14 @@ def _per_channel_rel(got, ref):
     return err / ref.abs().amax(dim=(0, 2, 3)).clamp_min(1e-300)
 
 
-@pytest.mark.parametrize("decades", [2, 3])
-def test_correlation_backward_per_channel_error(dev, decades):
+@pytest.mark.parametrize("decades,shape", [(2, (1, 256, 48, 64)), (3, (1, 256, 48, 64)), (3, (1, 128, 24, 136))])
+def test_correlation_backward_per_channel_error(dev, decades, shape):
     """Channel magnitudes spread log-uniformly over 10^-decades .. 10^+decades, independently per channel and input (FlowNetC is
     built with batchNorm=False: nothing ties the scales of conv3's 256 channels together).  The reference forms fp32 products at
     any scale (correlation_cuda_kernel.cu:214-229), so the error of gradInput[:, c] relative to the largest element OF THAT
     CHANNEL must not depend on how large the other channels are: each channel within 3x of the fp32 MFMA kernel's error for it."""
     import fn2_capi
-    B, C, H, W = 1, 256, 48, 64
+    B, C, H, W = shape                       # the last one: a map wider than 64 px (column-window kernel)
     g = torch.Generator().manual_seed(41 + decades)
     s1 = torch.pow(10.0, (torch.rand(C, generator=g) * 2 - 1) * decades).view(1, C, 1, 1)
     s2 = torch.pow(10.0, (torch.rand(C, generator=g) * 2 - 1) * decades).view(1, C, 1, 1)
