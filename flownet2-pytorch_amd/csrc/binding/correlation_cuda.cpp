@@ -90,6 +90,23 @@ int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor 
     gradInput1.resize_({B, C, H, W});        // correlation_cuda.cc:108-109; fully written, no fill_(0)
     gradInput2.resize_({B, C, H, W});
     TORCH_CHECK(gradInput1.is_contiguous() && gradInput2.is_contiguous(), op, ": gradInputs must be contiguous");
+    // Half tensors on maps wider than 64 px (Sintel-size conv3): there is no tiled half kernel for that corner (the narrow one holds
+    // whole rows of <= 64 px), and the general kernel takes milliseconds.  The fp32 column-window kernel on widened copies is
+    // ~25x faster and a superset numerically (exact products of the half operands, fp32 sums; the reference sums in half,
+    // correlation_cuda_kernel.cu:229): widen, run, narrow -- three elementwise passes around a 0.3 ms kernel instead of 9 ms.
+    if (dt == FN2_F16 && W > 64 && kernel_size == 1 && stride1 == 1 && stride2 == 2 && pad_size == max_displacement &&
+        max_displacement == 20 && C % 64 == 0 && H % 2 == 0 && W % 8 == 0) {
+        at::Tensor a32 = a.to(at::kFloat), b32 = b.to(at::kFloat), go32 = go.to(at::kFloat);
+        at::Tensor g1 = at::empty_like(a32), g2 = at::empty_like(b32);
+        const int rc = fn2_correlation_backward(a32.data_ptr(), b32.data_ptr(), go32.data_ptr(), g1.data_ptr(), g2.data_ptr(), FN2_F32,
+                                                B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                                current_stream(input1));
+        if (rc == FN2_OK) {
+            gradInput1.copy_(g1);
+            gradInput2.copy_(g2);
+            return 1;
+        }   // a shape the fp32 launchers decline: the half path below takes it
+    }
     check_rc(fn2_correlation_backward(a.data_ptr(), b.data_ptr(), go.data_ptr(), gradInput1.data_ptr(),
                                       gradInput2.data_ptr(), dt, B, C, H, W, pad_size, kernel_size, max_displacement,
                                       stride1, stride2, current_stream(input1)), op);

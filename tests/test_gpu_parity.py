@@ -1481,3 +1481,23 @@ def test_correlation_leakyrelu_cat_backward(dev, oracle):
                                  0, B, C, H, W, 20, 1, 20, 1, 2, 0, None)
     assert lib.fn2_correlation_backward_fused(*args(0.0, ws, 64)) == -1 and lib.fn2_correlation_backward_fused(*args(-0.1, ws, 64)) == -1
     assert lib.fn2_correlation_backward_fused(*args(0.1, ws, 64)) == -1
+
+
+def test_correlation_half_backward_wide_map_through_module(dev, oracle):
+    """Half tensors on a map wider than 64 px: the pybind module widens to fp32 around the column-window kernel instead of taking
+    the general one-lane-per-output kernel (9 ms at 8 x 256 x 56 x 128).  Against the oracle on the half-rounded inputs, within
+    half an ulp of each gradient's largest element (the result is rounded to half once)."""
+    import correlation_cuda
+    B, C, H, W = 1, 64, 16, 72
+    g = torch.Generator().manual_seed(91)
+    a = torch.randn(B, C, H, W, generator=g).half()
+    b = torch.randn(B, C, H, W, generator=g).half()
+    go = torch.randn(B, 441, H, W, generator=g).half()
+    r1, r2 = oracle.corr_bwd(a.float().numpy(), b.float().numpy(), go.float().numpy(), 20, 1, 20, 1, 2)
+    ad, bd, god = a.to(dev), b.to(dev), go.to(dev)
+    e = ad.new_empty
+    g1, g2, s1, s2 = e(0), e(0), e(0), e(0)
+    correlation_cuda.backward(ad, bd, s1, s2, god, g1, g2, 20, 1, 20, 1, 2, 1)
+    assert g1.dtype == torch.float16 and tuple(g1.shape) == (B, C, H, W)
+    for got, ref in ((g1, r1), (g2, r2)):
+        assert max_abs(got.float().cpu().numpy(), ref) <= 2.0 ** -10 * float(np.abs(ref).max()) + 1e-6
