@@ -414,10 +414,12 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const int tj = tk.flip ? 20 - 4 * U0 - bi + ai : 4 * U0 + bi - ai;                 // as g_dma
             const int ilg = tk.flip ? 4 * tk.rg - DR + 4 * U0 + bi : 4 * tk.rg + ai;
             const int x = 2 * (((((5 * ln) >> 1) & 31) * (p.W >> 1)) >> 5);
-            const int c = tk.cg * CG + ln, ilx = 4 * tk.rg - DR + 4 * U0 + (ln & 3);
+            const int c = tk.cg * CG + ln, ilx = min(4 * tk.rg + (ln & 3), HL - 1);   // X sample rows: two of the centre rows, clamped into the
+            // image -- every lane (= channel) gets four real values whatever the map's height (a lane without a sample would leave its
+            // channel unscaled: scripts/soak_fuzz.py, H = 2)
             const int ti = (5 * q + (ln & 3) + bi) % D;
             const unsigned ox = (ilx >= 0 && ilx < HL) ? (unsigned)((c * HW + (long)(2 * ilx + tk.py) * p.W + x) * 4) : 0x80000000u;
-            const int ilx2 = 4 * tk.rg - DR + 4 * U0 + ((ln + 2) & 3), xb = (x + (p.W >> 1)) >= p.W ? x + (p.W >> 1) - p.W : x + (p.W >> 1);
+            const int ilx2 = min(4 * tk.rg + ((ln + 2) & 3), HL - 1), xb = (x + (p.W >> 1)) >= p.W ? x + (p.W >> 1) - p.W : x + (p.W >> 1);
             const unsigned ox2 = (ilx2 >= 0 && ilx2 < HL) ? (unsigned)((c * HW + (long)(2 * ilx2 + tk.py) * p.W + xb) * 4) : 0x80000000u;
             const unsigned og = (ilg >= 0 && ilg < HL) ? (unsigned)((((tj * D + ti) * p.H + 2 * ilg + tk.py) * p.W + x) * 4) : 0x80000000u;
 #ifdef FN2_ABL_NOSAMPLELOAD   // timing ablation
@@ -428,13 +430,16 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             S.g = (VAR & 2) ? (u2)0x3f800000u : __builtin_amdgcn_raw_buffer_load_b64(rsg, (int)og, 0, 0);
 #endif
         };
-        // kx: THIS LANE'S channel -- the largest of its four sampled values lands in [1, 2) (typical values around 2^-1, where the
-        // mean-exponent rule of f16x2_split.h puts them; no non-zero sample: no scaling); kg: one exponent for the task, as before
+        // kx: THIS LANE'S channel; kg: one exponent for the task, as before
         auto sample_scales = [&](const Samp &S, int &kx, int &kg) {
-            const unsigned e0 = (S.x[0] >> 23) & 0xffu, e1 = (S.x[1] >> 23) & 0xffu, e2 = (S.x2[0] >> 23) & 0xffu, e3 = (S.x2[1] >> 23) & 0xffu;
-            const unsigned em = max(max(e0, e1), max(e2, e3));
-            const int k = 127 - (int)em;
-            kx = em == 0u ? 0 : (k < -126 ? -126 : k);
+            // this lane's channel: the MEAN binary exponent of its non-zero samples lands at 2^T_GEO = 2^-1, the rule of
+            // f16x2_split.h per channel (the mean, not the maximum: one outlier among the four must not push the channel's ordinary
+            // values into the f16 subnormals; four samples put the mean within about a bit of the channel's)
+            const unsigned t4 = exp_stat(S.x[0]) + exp_stat(S.x[1]) + exp_stat(S.x2[0]) + exp_stat(S.x2[1]);
+            const unsigned sum = t4 & 0xffffu, cnt = t4 >> 16;
+            const int em = cnt ? (int)((2u * sum + cnt) / (2u * cnt)) : 0;   // 1 .. 4 samples: a division by a small count
+            const int k = f16s::T_GEO + 127 - em;
+            kx = cnt == 0u ? 0 : (k < -126 ? -126 : k > 127 ? 127 : k);
             const unsigned tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
             kg = scale_exp(wave_sum(tg));
         };

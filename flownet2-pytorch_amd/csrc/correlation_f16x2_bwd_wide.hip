@@ -303,21 +303,27 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2_wide(Args p)
             // but never narrower than 8: a sample taken beyond the row reads zeros and would leave the channel unscaled)
             const int xs = 2 * (((5 * ln) >> 1) & 31), xs2 = (xs + 32) & 63;
             const int x = WPX * tk.xw + (WPX * tk.xw + xs < p.W ? xs : xs & 7);
-            const int c = tk.cg * CG + ln, ilx = 4 * tk.rg - DR + 4 * U0 + (ln & 3);
+            const int c = tk.cg * CG + ln, ilx = min(4 * tk.rg + (ln & 3), HL - 1);   // X sample rows: two of the centre rows, clamped into the
+            // image -- every lane (= channel) gets four real values whatever the map's height (a lane without a sample would leave its
+            // channel unscaled: scripts/soak_fuzz.py, H = 2)
             const int ti = (5 * q + (ln & 3) + bi) % D;
             const unsigned ox = (ilx >= 0 && ilx < HL && x < p.W) ? (unsigned)((c * HW + (long)(2 * ilx + tk.py) * p.W + x) * 4) : 0x80000000u;
-            const int ilx2 = 4 * tk.rg - DR + 4 * U0 + ((ln + 2) & 3), xb = WPX * tk.xw + (WPX * tk.xw + xs2 < p.W ? xs2 : xs2 & 7);
+            const int ilx2 = min(4 * tk.rg + ((ln + 2) & 3), HL - 1), xb = WPX * tk.xw + (WPX * tk.xw + xs2 < p.W ? xs2 : xs2 & 7);
             const unsigned ox2 = (ilx2 >= 0 && ilx2 < HL && xb < p.W) ? (unsigned)((c * HW + (long)(2 * ilx2 + tk.py) * p.W + xb) * 4) : 0x80000000u;
             const unsigned og = (ilg >= 0 && ilg < HL && x < p.W) ? (unsigned)((((tj * D + ti) * p.H + 2 * ilg + tk.py) * p.W + x) * 4) : 0x80000000u;
             S.x = __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox, 0, 0);
             S.x2 = __builtin_amdgcn_raw_buffer_load_b64(rsx, (int)ox2, 0, 0);
             S.g = __builtin_amdgcn_raw_buffer_load_b64(rsg, (int)og, 0, 0);
         };
-        auto sample_scales = [&](const Samp &S, int &kx, int &kg) {   // kx: this lane's channel (largest of four samples in [1, 2))
-            const unsigned e0 = (S.x[0] >> 23) & 0xffu, e1 = (S.x[1] >> 23) & 0xffu, e2 = (S.x2[0] >> 23) & 0xffu, e3 = (S.x2[1] >> 23) & 0xffu;
-            const unsigned em = max(max(e0, e1), max(e2, e3));
-            const int k = 127 - (int)em;
-            kx = em == 0u ? 0 : (k < -126 ? -126 : k);
+        auto sample_scales = [&](const Samp &S, int &kx, int &kg) {   // kx: this lane's channel
+            // this lane's channel: the MEAN binary exponent of its non-zero samples lands at 2^T_GEO = 2^-1, the rule of
+            // f16x2_split.h per channel (the mean, not the maximum: one outlier among the four must not push the channel's ordinary
+            // values into the f16 subnormals; four samples put the mean within about a bit of the channel's)
+            const unsigned t4 = exp_stat(S.x[0]) + exp_stat(S.x[1]) + exp_stat(S.x2[0]) + exp_stat(S.x2[1]);
+            const unsigned sum = t4 & 0xffffu, cnt = t4 >> 16;
+            const int em = cnt ? (int)((2u * sum + cnt) / (2u * cnt)) : 0;   // 1 .. 4 samples: a division by a small count
+            const int k = f16s::T_GEO + 127 - em;
+            kx = cnt == 0u ? 0 : (k < -126 ? -126 : k > 127 ? 127 : k);
             const unsigned tg = exp_stat(S.g[0]) + exp_stat(S.g[1]);
             kg = scale_exp(wave_sum(tg));
         };
