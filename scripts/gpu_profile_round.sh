@@ -9,7 +9,7 @@ TAG=${TAG:-rXX}
 OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp; R=$(pwd)
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench exit $?"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --model off > $R/$OUT/${TAG}_prof.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --model off --pmc off > $R/$OUT/${TAG}_prof.log 2>&1 )
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${TAG}_bench_kernel_stats.csv && head -12 "$f"
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   T=$(echo $C | tr ' ' '_'); rm -rf $OUT/${TAG}_pmc_$T

@@ -8,7 +8,7 @@ OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp; R=$(pwd)
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmcall_$C
-  ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/${TAG}_pmcall_$C -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --model off > $R/$OUT/${TAG}_pmcall_$C.log 2>&1 ); echo "pmc $C rc $?"
+  ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/${TAG}_pmcall_$C -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --model off --pmc off > $R/$OUT/${TAG}_pmcall_$C.log 2>&1 ); echo "pmc $C rc $?"
 done
 TAG=$TAG python - <<'PY'
 import collections, csv, glob, json, os
