@@ -72,6 +72,11 @@ enum {
                                 2^17 m (131072 m: the f16 maximum, 2^16, over 2^-1) do not fit the scaled f16; the outputs
                                 they touch are recomputed by a plain fp32 fma chain (slow, exact semantics incl. inf / nan).  Operands far BELOW m (< 2^-27 m) lose relative accuracy:
                                 block scaling is not scale-invariant within a task, unlike the reference's fp32 products.
+                                BACKWARD (since round 4): the in1 / in2 operand carries one scale PER CHANNEL (rows of the
+                                A matrix: removed exactly per gradient channel), so "m" above is the channel's own typical
+                                magnitude there -- channels of very different scale (no BatchNorm in FlowNetC) each keep
+                                fp32-class gradients (tests: channel magnitudes log-uniform over 10^+-3); gradOutput
+                                keeps one scale per task.
                                 Needs f32, k = 1, s1 = 1, s2 = 2, pad == md == 20, even H, W % 8 == 0 (any width: maps
                                 wider than 64 pixels -- Sintel-size inputs -- run column-window variants of the same kernels,
                                 csrc/correlation_f16x2_wide.hip / _bwd_wide.hip, ~1.5-1.7x the time per pixel),
