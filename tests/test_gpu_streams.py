@@ -1,0 +1,90 @@
+"""SURVEY.md 8(b) "streams / sync" and "threading": the modules launch on the caller's CURRENT stream, keep no global mutable
+state and are called from one Python worker thread per device or from the autograd engine's thread (reference:
+`correlation_cuda.cc:76,158`, `resample2d_kernel.cu:221`, `channelnorm_kernel.cu:113`; `main.py:189,200` DataParallel).
+Two threads, each on a stream of its own with its own inputs, run all three layers forward and backward several times at
+once; every result must be the one the same call gives alone on the default stream (the correlation and ChannelNorm kernels
+are deterministic: bit-identical; Resample2d's grad_img is summed with atomics: 1e-5)."""
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def layers(in1, in2, gcorr, img, flow, gwarp, gnorm):
+    import channelnorm_cuda
+    import correlation_cuda
+    import resample2d_cuda
+    e = in1.new_empty
+    s1, s2, out, g1, g2 = e(0), e(0), e(0), e(0), e(0)
+    p = (20, 1, 20, 1, 2, 1)
+    assert correlation_cuda.forward(in1, in2, s1, s2, out, *p) == 1
+    assert correlation_cuda.backward(in1, in2, s1, s2, gcorr, g1, g2, *p) == 1
+    warped = torch.zeros_like(img)
+    assert resample2d_cuda.forward(img, flow, warped, 1, True) == 1
+    gimg, gflow = torch.zeros_like(img), torch.zeros_like(flow)
+    assert resample2d_cuda.backward(img, flow, gwarp, gimg, gflow, 1, True) == 1
+    norm = torch.zeros_like(img[:, :1])
+    assert channelnorm_cuda.forward(warped, norm, 2) == 1
+    gdiff = torch.zeros_like(img)
+    assert channelnorm_cuda.backward(warped, norm, gnorm, gdiff, 2) == 1
+    return dict(out=out, g1=g1, g2=g2, warped=warped, gimg=gimg, gflow=gflow, norm=norm, gdiff=gdiff)
+
+
+def make(seed, dev, B, C, H, W, HI, WI):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    return (r(B, C, H, W), r(B, C, H, W), r(B, 441, H, W), r(B, 3, HI, WI) * 0.5, r(B, 2, HI, WI) * 4.0, r(B, 3, HI, WI),
+            r(B, 1, HI, WI))
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 48, 64, 384, 512), (1, 128, 24, 72, 96, 160)])
+def test_two_threads_two_streams(shape):
+    dev = torch.device("cuda:0")
+    args = [make(11 + i, dev, *shape) for i in range(2)]
+    alone = [layers(*a) for a in args]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+    start = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            st.wait_stream(torch.cuda.default_stream(dev))
+            with torch.cuda.stream(st):
+                start.wait()
+                for _ in range(6):
+                    r = layers(*args[i])
+                st.synchronize()
+            results[i] = r
+        except Exception as e:   # surfaced in the main thread
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for i in range(2):
+        for k, v in alone[i].items():
+            if k == "gimg":
+                assert float((results[i][k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), (i, k)
+            else:
+                assert torch.equal(results[i][k], v), (i, k)
+
+
+def test_side_stream_is_the_one_used():
+    """A call made under `torch.cuda.stream(s)` must be ordered on s: the kernel has to see a value that only a preceding
+    operation on s produces, and the default stream must not have to be synchronised for the result to be complete."""
+    import channelnorm_cuda
+    dev = torch.device("cuda:0")
+    s = torch.cuda.Stream(device=dev)
+    x = torch.zeros(4, 3, 384, 512, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for _ in range(20):
+            x.add_(1.0)            # queued on s; a kernel launched on another stream would race with these
+        out = torch.zeros(4, 1, 384, 512, device=dev)
+        assert channelnorm_cuda.forward(x, out, 2) == 1
+        s.synchronize()
+    assert torch.equal(out, torch.full_like(out, 20.0 * 3 ** 0.5).float()) or float((out - 20.0 * 3 ** 0.5).abs().max()) < 1e-4
