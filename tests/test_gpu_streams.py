@@ -88,3 +88,29 @@ def test_side_stream_is_the_one_used():
         assert channelnorm_cuda.forward(x, out, 2) == 1
         s.synchronize()
     assert torch.equal(out, torch.full_like(out, 20.0 * 3 ** 0.5).float()) or float((out - 20.0 * 3 ** 0.5).abs().max()) < 1e-4
+
+
+def test_layers_replay_from_a_hip_graph():
+    """The six launches of a step can be captured into a hipGraph (no synchronisation, no host-side state, no allocation the
+    capture cannot own) and replayed on new input VALUES in the same buffers; each replay equals the eager calls."""
+    dev = torch.device("cuda:0")
+    shape = (2, 256, 48, 64, 192, 256)
+    static = list(make(21, dev, *shape))
+    layers(*static)                      # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = layers(*static)
+    for seed in (22, 23):
+        fresh = make(seed, dev, *shape)
+        for dst, src in zip(static, fresh):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        eager = layers(*fresh)
+        torch.cuda.synchronize()
+        for k, v in eager.items():
+            if k == "gimg":
+                assert float((captured[k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), (seed, k)
+            else:
+                assert torch.equal(captured[k], v), (seed, k)
