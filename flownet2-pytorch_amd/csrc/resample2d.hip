@@ -892,6 +892,355 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     }
 }
 
+// ---------------------------------------------------------------- backward, three channels in one scatter
+// resample_bwd_tiled above walks the channels one at a time: per channel it rebuilds the weights and corner addresses of
+// every pixel, scatters, flushes, and reloads the image window -- seven barriers for C = 3.  FlowNet2 only warps 3-channel
+// images (models.py:133-174), so this variant keeps ALL THREE accumulation windows in LDS (fp32 cells, 3 x 24.8 KB = 74.5 KB:
+// still two workgroups per CU): a pixel's weights and addresses are formed once and its adds issued back to back --
+// channels 0 and 1 of a cell share one 64-bit word updated by ONE compare-and-swap, channel 2 has a word of its own: 8 LDS
+// atomics per pixel instead of 12 --; one flush pass; then the three image windows take the same LDS bytes and grad_flow is
+// gathered for all channels.  Four or five barriers.  Arithmetic and operation order per output as resample_bwd_tiled with
+// fp32 cells (the kernel of round 3); grad_flow is bit-identical to it.
+// Measured (scripts/resample_micro.py, 8 x 3 x 384 x 512, us; white-noise / smooth flow): loads, barriers and zeroing alone
+// 17 (resample_bwd_tiled: 26), + scatter 14 / 10, + flush 19 / 12: the flush -- 11.5 M device-scope atomics that leave the
+// XCD -- is the largest part and is bound chip-wide, which is why the order of the phases alternates between workgroups.
+__device__ __forceinline__ void lds_add_f32x2(unsigned long long *a, float v0, float v1)
+{
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        const float lo = __uint_as_float((unsigned)assumed) + v0, hi = __uint_as_float((unsigned)(assumed >> 32)) + v1;
+        old = atomicCAS(a, assumed, ((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo));
+    } while (old != assumed);
+}
+
+template <int TH, int TW, int R, int NT, int ORD>
+__global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__restrict__ img, ImgStrides is,
+                                                               const float *__restrict__ flow, const float *__restrict__ gout,
+                                                               float *__restrict__ gimg, float *__restrict__ gflow,
+                                                               int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int abl)
+{
+    constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT, CELLS = WH * WWP, C = 3;
+    constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[CELLS * 12];
+    float *const aw = reinterpret_cast<float *>(smem);                                 // all of it as floats (zeroing)
+    unsigned long long *const a01 = reinterpret_cast<unsigned long long *>(smem);       // [CELLS] (channel 0, channel 1) pairs + [CELLS] floats of channel 2
+    float *const a2 = reinterpret_cast<float *>(smem + CELLS * 8);
+    float *const iwin = reinterpret_cast<float *>(smem);                               // the same bytes, at another time: [3][WH * WW]
+    static_assert(3 * WH * WW * 4 <= CELLS * 12, "image windows must fit the accumulation windows' bytes");
+    enum { LIVE = 1, G_IN = 4, G_DX = 32, G_DY = 64 };
+
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    // The scatter + flush (LDS atomics, then fabric atomics) and the gather (window loads, LDS reads) use different parts of the
+    // machine and do not depend on each other, so half of the workgroups run the gather FIRST: the flushes of one half pass under
+    // the scatters of the other instead of all 512 resident workgroups flushing at once.  Which half: ORD 2 (shipped) alternates
+    // with the workgroup's index inside its XCD (i / 8; workgroups go to the XCDs round robin), ORD 1 with i / 256 (the second
+    // workgroup of every CU if CUs fill first slots first), ORD 0 never.  Measured, white-noise / smooth flow: ORD 0 50.7 / 40.8 us,
+    // ORD 1 53.8 / 36.5, ORD 2 51.0 / 37.7.  Only the overlap depends on where the dispatcher puts a workgroup, not the result.
+    const bool gather_first = ORD == 1 ? ((t >> 8) & 1) : ORD == 2 ? ((t >> 3) & 1) : false;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const long HW = (long)H * W, HWi = (long)Hi * Wi;
+
+    float fdx[PPT], fdy[PPT], go[PPT][C];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        const long p = ((x < W) && (y < H)) ? (long)y * W + x : 0;
+        fdx[k] = flow[(long)b * 2 * HW + p]; fdy[k] = flow[(long)b * 2 * HW + HW + p];
+#pragma unroll
+        for (int c = 0; c < C; ++c) go[k][c] = gout[((long)b * C + c) * HW + p];
+    }
+    f4 wreg[C][NW];
+    auto win_load = [&]() {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int i = tid + NT * j;
+                const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+                const int gy = wy0 + ly, gx = wx0 + lx;
+                f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+                if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                    v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
+                wreg[c][j] = v;
+            }
+    };
+    auto win_write = [&]() {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int i = tid + NT * j;
+                if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + c * (WH * WW) + 4 * i) = wreg[c][j];
+            }
+    };
+    auto zero = [&]() {
+        for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
+    };
+    auto scatter = [&]() {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            if (!((x < W) && (y < H)) || (abl & 2)) continue;
+            const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
+            const float fx = floorf(xf), fy = floorf(yf);
+            // weights by truncation (:105-106), corners clamped with the INPUT1 dims (:108-114)
+            const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
+            const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
+            const int xL = clampi(f2i_sat(fx), 0, Wi - 1), xR = clampi(f2i_sat(fx + 1.0f), 0, Wi - 1);
+            const int yT = clampi(f2i_sat(fy), 0, Hi - 1), yB = clampi(f2i_sat(fy + 1.0f), 0, Hi - 1);
+            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+            if ((lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH)) {
+                const int sb = lyT * WWP + lxL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WWP : 0;
+                {
+                    lds_add_f32x2(a01 + sb, s00 * go[k][0], s00 * go[k][1]);
+                    lds_add_f32x2(a01 + sb + ox, s01 * go[k][0], s01 * go[k][1]);
+                    lds_add_f32x2(a01 + sb + oy, s10 * go[k][0], s10 * go[k][1]);
+                    lds_add_f32x2(a01 + sb + oy + ox, s11 * go[k][0], s11 * go[k][1]);
+                    lds_add_f32(a2 + sb, s00 * go[k][2]);
+                    lds_add_f32(a2 + sb + ox, s01 * go[k][2]);
+                    lds_add_f32(a2 + sb + oy, s10 * go[k][2]);
+                    lds_add_f32(a2 + sb + oy + ox, s11 * go[k][2]);
+                }
+            } else {
+                const int sb = yT * Wi + xL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? Wi : 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float *G = gimg + ((long)b * C + c) * HWi + sb;
+                    unsafeAtomicAdd(G, s00 * go[k][c]);
+                    unsafeAtomicAdd(G + ox, s01 * go[k][c]);
+                    unsafeAtomicAdd(G + oy, s10 * go[k][c]);
+                    unsafeAtomicAdd(G + oy + ox, s11 * go[k][c]);
+                }
+            }
+        }
+    };
+    auto flush = [&]() {
+        if (abl & 1) return;
+        int ly = tid / WW, lx = tid - ly * WW;
+#pragma unroll 2
+        for (int i = tid; i < WH * WW; i += NT) {
+            const int gx = wx0 + lx, gy = wy0 + ly;
+            const int cell = ly * WWP + lx;
+            float v0, v1, v2;
+            {
+                const unsigned long long u = a01[cell];
+                v0 = __uint_as_float((unsigned)u); v1 = __uint_as_float((unsigned)(u >> 32)); v2 = a2[cell];
+            }
+            if (gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) {
+                float *G = gimg + (long)b * C * HWi + gy * Wi + gx;
+                if (v0 != 0.0f) unsafeAtomicAdd(G, v0);
+                if (v1 != 0.0f) unsafeAtomicAdd(G + HWi, v1);
+                if (v2 != 0.0f) unsafeAtomicAdd(G + 2 * HWi, v2);
+            }
+            ly += NT / WW; lx += NT % WW;
+            if (lx >= WW) { lx -= WW; ++ly; }
+        }
+    };
+    auto gather = [&]() {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            if (!((x < W) && (y < H))) continue;
+            const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
+            const float fx = floorf(xf), fy = floorf(yf);
+            const float gam_y = 1 - (xf - fx);   // c == 1 branch (:169)
+            const float gam_x = 1 - (yf - fy);   // c == 0 branch (:182)
+            // corners clamped with the FLOW dims (:163-166), then to the image
+            const int xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1), xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
+            const int yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1), yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
+            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+            const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            float out_dx = 0.0f, out_dy = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float g = go[k][c];
+                float iTL, iTR, iBL, iBR;
+                if (abl & 4) { iTL = iTR = iBL = iBR = g; }
+                else if (in) {
+                    const float *wc = iwin + c * (WH * WW) + lyT * WW + lxL;
+                    const int ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WW : 0;
+                    iTL = wc[0]; iTR = wc[ox]; iBL = wc[oy]; iBR = wc[oy + ox];
+                } else {
+                    const float *I = img + (long)b * is.b + (long)c * is.c;
+                    const int gb = yT * (int)is.h + xL * (int)is.w;
+                    const int ox = (xR != xL) ? (int)is.w : 0, oy = (yB != yT) ? (int)is.h : 0;
+                    iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
+                }
+                out_dy = out_dy + (gam_y * g) * iBL;       // (:172-177)
+                out_dy = out_dy - (gam_y * g) * iTL;
+                out_dy = out_dy + ((1 - gam_y) * g) * iBR;
+                out_dy = out_dy - ((1 - gam_y) * g) * iTR;
+                out_dx = out_dx + (gam_x * g) * iTR;       // (:185-190)
+                out_dx = out_dx - (gam_x * g) * iTL;
+                out_dx = out_dx + ((1 - gam_x) * g) * iBR;
+                out_dx = out_dx - ((1 - gam_x) * g) * iBL;
+            }
+            const long p = (long)y * W + x;
+            store_out(gflow + (long)b * 2 * HW + p, out_dx);
+            store_out(gflow + (long)b * 2 * HW + HW + p, out_dy);
+        }
+    };
+
+    if (!gather_first) {
+        for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
+        __syncthreads();
+
+        float gam_x[PPT], gam_y[PPT];
+        int gbase[PPT], flags[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            gam_x[k] = gam_y[k] = 0.0f;
+            gbase[k] = flags[k] = 0;
+            if (!((x < W) && (y < H))) continue;
+            int fl = LIVE;
+            const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
+            const float fx = floorf(xf), fy = floorf(yf);
+            const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
+            gam_y[k] = 1 - (xf - fx);   // c == 1 branch (:169)
+            gam_x[k] = 1 - (yf - fy);   // c == 0 branch (:182)
+            {   // gather corners: clamped with the FLOW dims (:163-166), then to the image
+                const int xL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), xR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
+                const int yT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), yB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
+                const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+                const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+                gbase[k] = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
+                fl |= (in ? G_IN : 0) | (xR != xL ? G_DX : 0) | (yB != yT ? G_DY : 0);
+            }
+            flags[k] = fl;
+            if (abl & 2) continue;
+            // scatter: weights by truncation (:105-106), corners clamped with the INPUT1 dims (:108-114)
+            const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
+            const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
+            const int xL = clampi(ixL, 0, Wi - 1), xR = clampi(ixR, 0, Wi - 1), yT = clampi(iyT, 0, Hi - 1), yB = clampi(iyB, 0, Hi - 1);
+            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+            if ((lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH)) {
+                const int sb = lyT * WWP + lxL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WWP : 0;
+                {
+                    lds_add_f32x2(a01 + sb, s00 * go[k][0], s00 * go[k][1]);
+                    lds_add_f32x2(a01 + sb + ox, s01 * go[k][0], s01 * go[k][1]);
+                    lds_add_f32x2(a01 + sb + oy, s10 * go[k][0], s10 * go[k][1]);
+                    lds_add_f32x2(a01 + sb + oy + ox, s11 * go[k][0], s11 * go[k][1]);
+                    lds_add_f32(a2 + sb, s00 * go[k][2]);
+                    lds_add_f32(a2 + sb + ox, s01 * go[k][2]);
+                    lds_add_f32(a2 + sb + oy, s10 * go[k][2]);
+                    lds_add_f32(a2 + sb + oy + ox, s11 * go[k][2]);
+                }
+            } else {
+                const int sb = yT * Wi + xL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? Wi : 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float *G = gimg + ((long)b * C + c) * HWi + sb;
+                    unsafeAtomicAdd(G, s00 * go[k][c]);
+                    unsafeAtomicAdd(G + ox, s01 * go[k][c]);
+                    unsafeAtomicAdd(G + oy, s10 * go[k][c]);
+                    unsafeAtomicAdd(G + oy + ox, s11 * go[k][c]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // the three image windows are requested now: their latency passes under the flush
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int i = tid + NT * j;
+                const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+                const int gy = wy0 + ly, gx = wx0 + lx;
+                f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+                if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                    v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
+                wreg[c][j] = v;
+            }
+        if (!(abl & 1)) {
+            int ly = tid / WW, lx = tid - ly * WW;
+#pragma unroll 2
+            for (int i = tid; i < WH * WW; i += NT) {
+                const int gx = wx0 + lx, gy = wy0 + ly;
+                const int cell = ly * WWP + lx;
+                float v0, v1, v2;
+                {
+                    const unsigned long long u = a01[cell];
+                    v0 = __uint_as_float((unsigned)u); v1 = __uint_as_float((unsigned)(u >> 32)); v2 = a2[cell];
+                }
+                if (gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) {
+                    float *G = gimg + (long)b * C * HWi + gy * Wi + gx;
+                    if (v0 != 0.0f) unsafeAtomicAdd(G, v0);
+                    if (v1 != 0.0f) unsafeAtomicAdd(G + HWi, v1);
+                    if (v2 != 0.0f) unsafeAtomicAdd(G + 2 * HWi, v2);
+                }
+                ly += NT / WW; lx += NT % WW;
+                if (lx >= WW) { lx -= WW; ++ly; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int i = tid + NT * j;
+                if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + c * (WH * WW) + 4 * i) = wreg[c][j];
+            }
+        __syncthreads();
+
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int fl = flags[k], gb = gbase[k];
+            if (!(fl & LIVE)) continue;
+            float out_dx = 0.0f, out_dy = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float g = go[k][c];
+                float iTL, iTR, iBL, iBR;
+                if (abl & 4) { iTL = iTR = iBL = iBR = g; }
+                else if (fl & G_IN) {
+                    const float *wc = iwin + c * (WH * WW);
+                    const int ox = (fl & G_DX) ? 1 : 0, oy = (fl & G_DY) ? WW : 0;
+                    iTL = wc[gb]; iTR = wc[gb + ox]; iBL = wc[gb + oy]; iBR = wc[gb + oy + ox];
+                } else {
+                    const float *I = img + (long)b * is.b + (long)c * is.c;
+                    const int ox = (fl & G_DX) ? (int)is.w : 0, oy = (fl & G_DY) ? (int)is.h : 0;
+                    iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
+                }
+                out_dy = out_dy + (gam_y[k] * g) * iBL;       // (:172-177)
+                out_dy = out_dy - (gam_y[k] * g) * iTL;
+                out_dy = out_dy + ((1 - gam_y[k]) * g) * iBR;
+                out_dy = out_dy - ((1 - gam_y[k]) * g) * iTR;
+                out_dx = out_dx + (gam_x[k] * g) * iTR;       // (:185-190)
+                out_dx = out_dx - (gam_x[k] * g) * iTL;
+                out_dx = out_dx + ((1 - gam_x[k]) * g) * iBR;
+                out_dx = out_dx - ((1 - gam_x[k]) * g) * iBL;
+            }
+            const int idx = tid + NT * k;
+            const int x = X0 + idx % TW, y = Y0 + idx / TW;
+            const long p = (long)y * W + x;
+            store_out(gflow + (long)b * 2 * HW + p, out_dx);
+            store_out(gflow + (long)b * 2 * HW + HW + p, out_dy);
+        }
+    } else {
+        win_load();
+        win_write();
+        __syncthreads();
+        gather();
+        __syncthreads();
+        zero();
+        __syncthreads();
+        scatter();
+        __syncthreads();
+        flush();
+    }
+}
+
 // N2 for shapes the tiled kernel does not take: one lane per pixel, corners gathered from global memory.
 __global__ __launch_bounds__(256) void warp_diff_norm_cat_kernel(const float *__restrict__ pair, const float *__restrict__ flow,
                                                                  float *__restrict__ out, int C, int H, int W, long npix,
@@ -1087,7 +1436,16 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
     } while (0)
         // bits 12-13: tile height (profiling: 1 = 48, 2 = 32, 3 = 64), 0 = automatic; bits 14-15: accumulation window
         // (profiling: 1 = fp64 cells 48 x 64 +- 12, 2 = fp64 cells 32 x 64 +- 16, 3 = fp64 cells 48 x 64 +- 16, one workgroup per CU)
+#define FN2_RC3(ORD)                                                                                                      \
+    do {                                                                                                               \
+        const int tiles_y = (H + 31) / 32;                                                                             \
+        hipLaunchKernelGGL((resample_bwd_tiled_c3<32, TW, 16, 1024, ORD>), dim3((unsigned)((long)B * tiles_x * tiles_y)), \
+                           dim3(1024), 0, s, img, is, flow, grad_out, grad_img, grad_flow, Hi, Wi, H, W, tiles_x,      \
+                           tiles_y, abl);                                                                              \
+    } while (0)
         switch ((bilinear >> 12) & 15) {
+        case 13: if (C == 3) FN2_RC3(0); else FN2_RB(32, 16, 8, 1); break;   // profiling: every workgroup scatters first
+        case 14: if (C == 3) FN2_RC3(1); else FN2_RB(32, 16, 8, 1); break;   // profiling: order alternates with i / 256
         case 1: FN2_RB(48, 16, 8, 0); break;
         case 2: FN2_RB(32, 16, 8, 0); break;
         case 3: FN2_RB(64, 16, 8, 0); break;
@@ -1099,11 +1457,13 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
         case 7: FN2_RB(96, 16, 4, 1); break;
         case 9: FN2_RB(48, 16, 4, 0); break;
         case 10: if (tile_height(B, H, tiles_x) == 48) FN2_RB(48, 16, 8, 0); else FN2_RB(32, 16, 8, 0); break;   // the round-3 choice
-        // 32-row tiles with fp64 cells (74 KB of LDS: two workgroups per CU): measured fastest on both test flows -- 8 x 3 x 384 x 512,
-        // white-noise flow 53.8 us against 57.2-59.8 us for 48 x 64 fp32 cells in one round of workgroups, smooth flow 38.4 against 44.5
-        default: FN2_RB(32, 16, 8, 1); break;
+        // C == 3 (FlowNet2's only use): the three channels in one scatter, workgroup order alternating with i / 8 -- 8 x 3 x 384 x 512,
+        // white-noise flow 51.0 us, smooth flow 37.7.  Other C: one channel at a time, 32-row tiles with fp64 cells (74 KB of LDS, two
+        // workgroups per CU; selector 8): 54.2 / 38.6 us against 57.2-59.8 / 44.5 for the 48 x 64 fp32 tiles of round 3 (selector 10)
+        default: if (C == 3) FN2_RC3(2); else FN2_RB(32, 16, 8, 1); break;
         }
 #undef FN2_RB
+#undef FN2_RC3
     } else {
         hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out,
                            grad_img, grad_flow, C, Hi, Wi, H, W, npix);

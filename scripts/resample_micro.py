@@ -35,13 +35,13 @@ for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth
             ref_out = out.clone()
         print("   %-28s %.1f us   max |d| vs the first row %.2e" % (lab, t, float((out - ref_out).abs().max())))
     ref = None
-    for flags, lab in ((1, "bwd tiled (default)"), (1 | 0xA000, "bwd tiled, round-3 choice"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"),
+    for flags, lab in ((1, "bwd (default: 3 channels at once)"), (1 | 0xA000, "bwd tiled, round-3 choice"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"),
                        (1 | 0x5000, "bwd 48x64 +-12 f32 CAS"), (1 | 0x4000, "bwd 48x64 +-12 fp64 cells"), (1 | 0x8000, "bwd 32x64 +-16 fp64 cells"),
-                       (1 | 0xC000, "bwd 48x64 +-16 fp64, 1 WG/CU"), (1 | 0x9000, "bwd 48x64 +-16 f32, 1 WG/CU"),
+                       (1 | 0xD000, "3ch, every workgroup scatters first"), (1 | 0xE000, "3ch, order alternates with i/256"), (1 | 0xD000 | 0x200, "3ch scatter first, no flush"), (1 | 0xD000 | 0x400, "3ch scatter first, no scatter"), (1 | 0xD000 | 0xE00, "3ch scatter first, none of them"), (1 | 0xC000, "bwd 48x64 +-16 fp64, 1 WG/CU"), (1 | 0x9000, "bwd 48x64 +-16 f32, 1 WG/CU"),
                        (1 | 0x6000, "bwd 96x64 +-16 f32, 1 WG/CU"), (1 | 0x7000, "bwd 96x64 +-16 fp64, 1 WG/CU"),
                        (1 | 0x4000 | 0x200, "fp64 48x64+-12, no flush"), (1 | 0x4000 | 0x400, "fp64 48x64+-12, no scatter"),
-                       (1 | 0x200, "bwd tiled, no flush"), (1 | 0x400, "bwd tiled, no scatter"), (1 | 0x800, "bwd tiled, no img gather"),
-                       (1 | 0xE00, "bwd tiled, none of them"), (1 | 0x100, "bwd untiled")):
+                       (1 | 0x8200, "fp64 32x64, no flush"), (1 | 0x8400, "fp64 32x64, no scatter"), (1 | 0x8800, "fp64 32x64, no img gather"),
+                       (1 | 0x8E00, "fp64 32x64, none of them"), (1 | 0x100, "bwd untiled")):
         def run():
             gimg.zero_()
             lib.fn2_debug_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, 1, flags & ~0xff, st)
