@@ -28,7 +28,7 @@ def timeit(fn, n=20):
     return ts[len(ts) // 2]
 for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth)):
     print(name)
-    for flags, lab in ((1, "fwd tiled"), (1 | 0x1000, "fwd tiled 48x64"), (1 | 0x2000, "fwd tiled 32x64"), (1 | 0x3000, "fwd 96x64, 3 windows resident"), (1 | 0x4000, "fwd 48x64, 4 px per thread"), (1 | 0x8000, "fwd 64x64, 4 px per thread"), (1 | 0x100, "fwd untiled")):
+    for flags, lab in ((1, "fwd (default: 3 windows resident, 32x64)"), (1 | 0x1000, "fwd per channel 48x64"), (1 | 0x2000, "fwd per channel 32x64"), (1 | 0x3000, "fwd 96x64, 3 windows resident"), (1 | 0x4000, "fwd 48x64, 4 px per thread"), (1 | 0x8000, "fwd 64x64, 4 px per thread"), (1 | 0x100, "fwd untiled")):
         t = timeit(lambda: lib.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
         torch.cuda.synchronize()
         if flags == 1:
