@@ -129,6 +129,34 @@ def test_resample2d(dev, oracle, shape, bilinear):
     assert max_abs(gimg.cpu().numpy(), rimg) <= TOL     # fp32 atomics: order differs from the oracle's
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 32), (2, 100, 200), (1, 33, 68), (3, 64, 64), (2, 97, 260), (1, 48, 96)])
+@pytest.mark.parametrize("spread", [0.5, 4.0, 40.0])
+def test_resample2d_three_channel_kernels(dev, oracle, shape, spread):
+    """C = 3 on tileable maps (W % 4 == 0, H >= 16, W >= 32) takes the kernels that hold all three channel windows in LDS at once
+    (forward: `resample_fwd_tiled_all`; backward: `resample_bwd_tiled_c3`, two channels per 64-bit compare-and-swap, phase order
+    alternating between workgroups).  Ragged tiles in both directions, the smallest tileable map, flows inside the +-16 px window
+    (0.5, 4 px), mostly outside it (40 px: global atomics / global gathers) and 1 % outliers; read through the strides of a
+    channel slice as models.py:133 passes it; the backward accumulates into a non-zero grad_input1 (resample2d.py:31)."""
+    import resample2d_cuda
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    x = torch.rand(B, 6, H, W, generator=g) - 0.5
+    flow = _flow(g, (B, 2, H, W), spread)
+    gout = torch.randn(B, 3, H, W, generator=g)
+    view = x.to(dev)[:, 3:]
+    img = np.ascontiguousarray(x[:, 3:].numpy())
+    for bilinear in (True, False):
+        out = torch.full((B, 3, H, W), float("nan"), device=dev)
+        assert resample2d_cuda.forward(view, flow.to(dev), out, 1, bilinear) == 1
+        assert max_abs(out.cpu().numpy(), oracle.resample_fwd(img, flow.numpy(), 1, bilinear)) <= 1e-6
+    gimg = torch.ones(B, 3, H, W, device=dev)
+    gflow = torch.full((B, 2, H, W), float("nan"), device=dev)
+    assert resample2d_cuda.backward(view, flow.to(dev), gout.to(dev), gimg, gflow, 1, True) == 1
+    rimg, rflow = oracle.resample_bwd(img, flow.numpy(), gout.numpy(), 1, True)
+    assert max_abs(gflow.cpu().numpy(), rflow) <= 1e-6
+    assert max_abs(gimg.cpu().numpy() - 1.0, rimg) <= 2e-6 * max(1.0, float(np.abs(rimg).max()))
+
+
 def test_resample2d_strided_image_and_accumulate(dev, oracle):
     """The kernel reads input1 through its strides (models.py:133 passes x[:, 3:, :, :]) and the
     backward ACCUMULATES into grad_input1 (caller zero-fills, resample2d.py:31)."""
