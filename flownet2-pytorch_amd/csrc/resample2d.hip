@@ -690,6 +690,44 @@ __global__ __launch_bounds__(1024, WPE) void resample_fwd_tiled_all(const float 
     }
 }
 
+// The backward windows FOLLOW the flow.  A tile's accumulation / image window is tile +- R px around where the tile's pixels LAND,
+// not around the tile: real flow fields are locally smooth but not small (FlowNet2 warps by the estimated motion, tens of pixels on
+// Sintel), and with a window centred on the tile a translation of (25, -18) px sends every corner to the global-atomic path -- 760 us
+// instead of 38 for the same field without the translation (8 x 3 x 384 x 512).  The offset is a robust centre of the flow at four
+// pixels of the tile (its quadrant centres): per component the mean of the two middle values if they
+// agree, so that one or two outliers among the four change nothing -- the plain mean moved 4 % of the tiles of the SURVEY's white-noise flow (1 % of its
+// values are x20) far away from their pixels: 51 -> 77 us.  It is rounded -- to a multiple of 4 px in x, so that the 16-byte groups of
+// the image window stay aligned -- and zero below 8 px, which leaves small flows exactly where they were.  Only the placement of the
+// window depends on it; which pixels take the LDS path never changes a result beyond the order of the fp32 sums of grad_input1.
+struct TileFlowSample { float v; };   // lane l holds component (l >> 2) & 1 of sample pixel l & 3
+__device__ __forceinline__ void tile_flow_sample(const float *__restrict__ flow_b, long HW, int X0, int Y0, int TW, int TH, int H, int W,
+                                                 TileFlowSample &S)
+{
+    // ONE vector load per wave (eight scalar loads per wave through the scalar cache cost the kernel 4 us)
+    const int l = threadIdx.x & 7, q = l & 3;
+    const int sx = min(X0 + TW / 4 + (q & 1) * (TW / 2), W - 1), sy = min(Y0 + TH / 4 + (q >> 1) * (TH / 2), H - 1);
+    S.v = flow_b[((l >> 2) ? HW : 0) + (long)sy * W + sx];
+}
+// the two middle values of four: their mean if they agree within 8 px, else "no estimate" (two of the four were outliers)
+__device__ __forceinline__ float middle_of_four(const float v[4])
+{
+    const float a = fminf(v[0], v[1]), b = fmaxf(v[0], v[1]), c = fminf(v[2], v[3]), d = fmaxf(v[2], v[3]);
+    const float m1 = fmaxf(a, c), m2 = fminf(b, d);
+    return fabsf(m1 - m2) < 8.0f ? 0.5f * (m1 + m2) : 0.0f;
+}
+__device__ __forceinline__ void tile_window_offset(const TileFlowSample &S, int &offx, int &offy)
+{
+    float sx[4], sy[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sx[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(S.v), q));
+        sy[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(S.v), 4 + q));
+    }
+    const float mx = middle_of_four(sx), my = middle_of_four(sy);
+    offx = (fabsf(mx) >= 8.0f && fabsf(mx) < 1.0e6f) ? 4 * (int)rintf(mx * 0.25f) : 0;
+    offy = (fabsf(my) >= 8.0f && fabsf(my) < 1.0e6f) ? (int)rintf(my) : 0;
+}
+
 template <int TH, int TW, int R, int NT, int WPE, int ACC = 0>
 __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__restrict__ img, ImgStrides is,
                                                             const float *__restrict__ flow,
@@ -716,8 +754,11 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const int X0 = tx * TW, Y0 = ty * TH;
     const long HW = (long)H * W, HWi = (long)Hi * Wi;
+    TileFlowSample tfs;
+    tile_flow_sample(flow + (long)b * 2 * HW, HW, X0, Y0, TW, TH, H, W, tfs);
+    int wx0, wy0;   // set below, once the thread's own loads have been requested
 
     // per-pixel state (flow is read once)
     float alpha[PPT], beta[PPT], gam_x[PPT], gam_y[PPT], out_dx[PPT], out_dy[PPT];
@@ -747,8 +788,8 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
             if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + 4 * i) = wreg[j];
         }
     };
-    // all flow values of the thread are requested before the first one is used (one memory round trip instead of PPT), and
-    // the first image window right behind them: none of these addresses depends on the flow
+    // all flow values of the thread are requested before the first one is used (one memory round trip instead of PPT); the
+    // window's place follows from the tile's flow sample, requested before them, and the first image window goes out right behind
     float fdx[PPT], fdy[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -758,7 +799,17 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
         const long p = in ? (long)y * W + x : 0;
         fdx[k] = flow[(long)b * 2 * HW + p]; fdy[k] = flow[(long)b * 2 * HW + HW + p];
     }
+    wx0 = X0 - R; wy0 = Y0 - R;
     if (C > 0) win_load(img + (long)b * is.b);
+    __builtin_amdgcn_sched_barrier(0);
+    {   // requested where the tile is, and once more if the flow sample says its pixels land elsewhere (never for flows below 8 px)
+        int offx, offy;
+        tile_window_offset(tfs, offx, offy);
+        if (offx | offy) {
+            wx0 += offx; wy0 += offy;
+            if (C > 0) win_load(img + (long)b * is.b);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
@@ -899,11 +950,13 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
 // still two workgroups per CU): a pixel's weights and addresses are formed once and its adds issued back to back --
 // channels 0 and 1 of a cell share one 64-bit word updated by ONE compare-and-swap, channel 2 has a word of its own: 8 LDS
 // atomics per pixel instead of 12 --; one flush pass; then the three image windows take the same LDS bytes and grad_flow is
-// gathered for all channels.  Four or five barriers.  Arithmetic and operation order per output as resample_bwd_tiled with
-// fp32 cells (the kernel of round 3); grad_flow is bit-identical to it.
+// gathered for all channels.  Four barriers.  Arithmetic and operation order per output as resample_bwd_tiled with fp32 cells
+// (the kernel of round 3); grad_flow is bit-identical to it.
 // Measured (scripts/resample_micro.py, 8 x 3 x 384 x 512, us; white-noise / smooth flow): loads, barriers and zeroing alone
 // 17 (resample_bwd_tiled: 26), + scatter 14 / 10, + flush 19 / 12: the flush -- 11.5 M device-scope atomics that leave the
-// XCD -- is the largest part and is bound chip-wide, which is why the order of the phases alternates between workgroups.
+// XCD, bound chip-wide -- is the largest part.  (Half of the workgroups running the gather first, so that their flushes pass
+// under the others' scatters, gained 3 us on the smooth flow and nothing on the white-noise one, and the kernel's time moved by
+// +-3 us with the mere layout of that second path's code: one order, straight-line text.)
 __device__ __forceinline__ void lds_add_f32x2(unsigned long long *a, float v0, float v1)
 {
     unsigned long long old = *a, assumed;
@@ -914,7 +967,40 @@ __device__ __forceinline__ void lds_add_f32x2(unsigned long long *a, float v0, f
     } while (old != assumed);
 }
 
-template <int TH, int TW, int R, int NT, int ORD>
+// The 12 adds of one pixel into the three accumulation windows.  `pile`: a corner was clamped to the image border in a wave where
+// at least 8 lanes were -- clamping sends whole runs of pixels to ONE cell (a translation of 25 px puts 25 lanes of a wave on the last
+// column; the stray outlier of a noisy flow does not count: a wave that takes this path pays for it with all its lanes).  A
+// compare-and-swap loop retries once per colliding lane and a round trip each -- 790 us for the translated field of tile_window_offset's note --, so these
+// pixels use the LDS's own fp32 add: 0.33 lane-atomics/clk/CU, 7x slower than the loop without collisions, but collisions are
+// resolved inside the LDS unit.  It may touch one half of a 64-bit pair another lane updates by compare-and-swap: both are single
+// LDS operations, and the swap fails and retries if the word changed under it.
+__device__ __forceinline__ void c3_add_pixel(unsigned long long *a01, float *a2, int sb, int ox, int oy, float s00, float s01,
+                                             float s10, float s11, float g0, float g1, float g2, bool pile)
+{
+    if (!pile) {
+        lds_add_f32x2(a01 + sb, s00 * g0, s00 * g1);
+        lds_add_f32x2(a01 + sb + ox, s01 * g0, s01 * g1);
+        lds_add_f32x2(a01 + sb + oy, s10 * g0, s10 * g1);
+        lds_add_f32x2(a01 + sb + oy + ox, s11 * g0, s11 * g1);
+        lds_add_f32(a2 + sb, s00 * g2);
+        lds_add_f32(a2 + sb + ox, s01 * g2);
+        lds_add_f32(a2 + sb + oy, s10 * g2);
+        lds_add_f32(a2 + sb + oy + ox, s11 * g2);
+    } else {
+        typedef __attribute__((address_space(3))) float lds_float;
+        lds_float *p01 = (lds_float *)a01, *p2 = (lds_float *)a2;
+        const int cell[4] = {sb, sb + ox, sb + oy, sb + oy + ox};
+        const float s[4] = {s00, s01, s10, s11};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_ds_faddf(p01 + 2 * cell[i], s[i] * g0, 0, 0, false);
+            __builtin_amdgcn_ds_faddf(p01 + 2 * cell[i] + 1, s[i] * g1, 0, 0, false);
+            __builtin_amdgcn_ds_faddf(p2 + cell[i], s[i] * g2, 0, 0, false);
+        }
+    }
+}
+
+template <int TH, int TW, int R, int NT>
 __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__restrict__ img, ImgStrides is,
                                                                const float *__restrict__ flow, const float *__restrict__ gout,
                                                                float *__restrict__ gimg, float *__restrict__ gflow,
@@ -932,18 +1018,13 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
 
     const int tid = threadIdx.x;
     int t = blockIdx.x;
-    // The scatter + flush (LDS atomics, then fabric atomics) and the gather (window loads, LDS reads) use different parts of the
-    // machine and do not depend on each other, so half of the workgroups run the gather FIRST: the flushes of one half pass under
-    // the scatters of the other instead of all 512 resident workgroups flushing at once.  Which half: ORD 2 (shipped) alternates
-    // with the workgroup's index inside its XCD (i / 8; workgroups go to the XCDs round robin), ORD 1 with i / 256 (the second
-    // workgroup of every CU if CUs fill first slots first), ORD 0 never.  Measured, white-noise / smooth flow: ORD 0 50.7 / 40.8 us,
-    // ORD 1 53.8 / 36.5, ORD 2 51.0 / 37.7.  Only the overlap depends on where the dispatcher puts a workgroup, not the result.
-    const bool gather_first = ORD == 1 ? ((t >> 8) & 1) : ORD == 2 ? ((t >> 3) & 1) : false;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    const int X0 = tx * TW, Y0 = ty * TH;
     const long HW = (long)H * W, HWi = (long)Hi * Wi;
+    TileFlowSample tfs;
+    tile_flow_sample(flow + (long)b * 2 * HW, HW, X0, Y0, TW, TH, H, W, tfs);
 
     float fdx[PPT], fdy[PPT], go[PPT][C];
 #pragma unroll
@@ -955,74 +1036,77 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
 #pragma unroll
         for (int c = 0; c < C; ++c) go[k][c] = gout[((long)b * C + c) * HW + p];
     }
-    f4 wreg[C][NW];
-    auto win_load = [&]() {
+    for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);   // all of that goes out before the wave waits for its flow sample
+    int offx, offy;
+    tile_window_offset(tfs, offx, offy);
+    const int wx0 = X0 - R + offx, wy0 = Y0 - R + offy;
+    __syncthreads();
+
+    float gam_x[PPT], gam_y[PPT];
+    int gbase[PPT], flags[PPT];
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int i = tid + NT * j;
-                const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
-                const int gy = wy0 + ly, gx = wx0 + lx;
-                f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-                if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
-                    v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
-                wreg[c][j] = v;
-            }
-    };
-    auto win_write = [&]() {
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int i = tid + NT * j;
-                if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + c * (WH * WW) + 4 * i) = wreg[c][j];
-            }
-    };
-    auto zero = [&]() {
-        for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
-    };
-    auto scatter = [&]() {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int idx = tid + NT * k;
-            const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            if (!((x < W) && (y < H)) || (abl & 2)) continue;
-            const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
-            const float fx = floorf(xf), fy = floorf(yf);
-            // weights by truncation (:105-106), corners clamped with the INPUT1 dims (:108-114)
-            const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
-            const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
-            const int xL = clampi(f2i_sat(fx), 0, Wi - 1), xR = clampi(f2i_sat(fx + 1.0f), 0, Wi - 1);
-            const int yT = clampi(f2i_sat(fy), 0, Hi - 1), yB = clampi(f2i_sat(fy + 1.0f), 0, Hi - 1);
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        gam_x[k] = gam_y[k] = 0.0f;
+        gbase[k] = flags[k] = 0;
+        if (!((x < W) && (y < H))) continue;
+        int fl = LIVE;
+        const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
+        const float fx = floorf(xf), fy = floorf(yf);
+        const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
+        gam_y[k] = 1 - (xf - fx);   // c == 1 branch (:169)
+        gam_x[k] = 1 - (yf - fy);   // c == 0 branch (:182)
+        {   // gather corners: clamped with the FLOW dims (:163-166), then to the image
+            const int xL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), xR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
+            const int yT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), yB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
             const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-            if ((lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH)) {
-                const int sb = lyT * WWP + lxL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WWP : 0;
-                {
-                    lds_add_f32x2(a01 + sb, s00 * go[k][0], s00 * go[k][1]);
-                    lds_add_f32x2(a01 + sb + ox, s01 * go[k][0], s01 * go[k][1]);
-                    lds_add_f32x2(a01 + sb + oy, s10 * go[k][0], s10 * go[k][1]);
-                    lds_add_f32x2(a01 + sb + oy + ox, s11 * go[k][0], s11 * go[k][1]);
-                    lds_add_f32(a2 + sb, s00 * go[k][2]);
-                    lds_add_f32(a2 + sb + ox, s01 * go[k][2]);
-                    lds_add_f32(a2 + sb + oy, s10 * go[k][2]);
-                    lds_add_f32(a2 + sb + oy + ox, s11 * go[k][2]);
-                }
-            } else {
-                const int sb = yT * Wi + xL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? Wi : 0;
+            const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
+            gbase[k] = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
+            fl |= (in ? G_IN : 0) | (xR != xL ? G_DX : 0) | (yB != yT ? G_DY : 0);
+        }
+        flags[k] = fl;
+        if (abl & 2) continue;
+        // scatter: weights by truncation (:105-106), corners clamped with the INPUT1 dims (:108-114)
+        const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
+        const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
+        const int xL = clampi(ixL, 0, Wi - 1), xR = clampi(ixR, 0, Wi - 1), yT = clampi(iyT, 0, Hi - 1), yB = clampi(iyB, 0, Hi - 1);
+        const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
+        if ((lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH)) {
+            const int sb = lyT * WWP + lxL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WWP : 0;
+            const bool moved = (xL != ixL) || (xR != ixR) || (yT != iyT) || (yB != iyB);   // a corner was clamped to the border
+            c3_add_pixel(a01, a2, sb, ox, oy, s00, s01, s10, s11, go[k][0], go[k][1], go[k][2],
+                         moved && __popcll(__ballot(moved)) >= 8);
+        } else {
+            const int sb = yT * Wi + xL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? Wi : 0;
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float *G = gimg + ((long)b * C + c) * HWi + sb;
-                    unsafeAtomicAdd(G, s00 * go[k][c]);
-                    unsafeAtomicAdd(G + ox, s01 * go[k][c]);
-                    unsafeAtomicAdd(G + oy, s10 * go[k][c]);
-                    unsafeAtomicAdd(G + oy + ox, s11 * go[k][c]);
-                }
+            for (int c = 0; c < C; ++c) {
+                float *G = gimg + ((long)b * C + c) * HWi + sb;
+                unsafeAtomicAdd(G, s00 * go[k][c]);
+                unsafeAtomicAdd(G + ox, s01 * go[k][c]);
+                unsafeAtomicAdd(G + oy, s10 * go[k][c]);
+                unsafeAtomicAdd(G + oy + ox, s11 * go[k][c]);
             }
         }
-    };
-    auto flush = [&]() {
-        if (abl & 1) return;
+    }
+    __syncthreads();
+
+    // the three image windows are requested now: their latency passes under the flush
+    f4 wreg[C][NW];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
+            wreg[c][j] = v;
+        }
+    if (!(abl & 1)) {
         int ly = tid / WW, lx = tid - ly * WW;
 #pragma unroll 2
         for (int i = tid; i < WH * WW; i += NT) {
@@ -1042,202 +1126,50 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
             ly += NT / WW; lx += NT % WW;
             if (lx >= WW) { lx -= WW; ++ly; }
         }
-    };
-    auto gather = [&]() {
+    }
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int idx = tid + NT * k;
-            const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            if (!((x < W) && (y < H))) continue;
-            const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
-            const float fx = floorf(xf), fy = floorf(yf);
-            const float gam_y = 1 - (xf - fx);   // c == 1 branch (:169)
-            const float gam_x = 1 - (yf - fy);   // c == 0 branch (:182)
-            // corners clamped with the FLOW dims (:163-166), then to the image
-            const int xL = clampi(clampi(f2i_sat(fx), 0, W - 1), 0, Wi - 1), xR = clampi(clampi(f2i_sat(fx + 1.0f), 0, W - 1), 0, Wi - 1);
-            const int yT = clampi(clampi(f2i_sat(fy), 0, H - 1), 0, Hi - 1), yB = clampi(clampi(f2i_sat(fy + 1.0f), 0, H - 1), 0, Hi - 1);
-            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-            const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
-            float out_dx = 0.0f, out_dy = 0.0f;
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float g = go[k][c];
-                float iTL, iTR, iBL, iBR;
-                if (abl & 4) { iTL = iTR = iBL = iBR = g; }
-                else if (in) {
-                    const float *wc = iwin + c * (WH * WW) + lyT * WW + lxL;
-                    const int ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WW : 0;
-                    iTL = wc[0]; iTR = wc[ox]; iBL = wc[oy]; iBR = wc[oy + ox];
-                } else {
-                    const float *I = img + (long)b * is.b + (long)c * is.c;
-                    const int gb = yT * (int)is.h + xL * (int)is.w;
-                    const int ox = (xR != xL) ? (int)is.w : 0, oy = (yB != yT) ? (int)is.h : 0;
-                    iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
-                }
-                out_dy = out_dy + (gam_y * g) * iBL;       // (:172-177)
-                out_dy = out_dy - (gam_y * g) * iTL;
-                out_dy = out_dy + ((1 - gam_y) * g) * iBR;
-                out_dy = out_dy - ((1 - gam_y) * g) * iTR;
-                out_dx = out_dx + (gam_x * g) * iTR;       // (:185-190)
-                out_dx = out_dx - (gam_x * g) * iTL;
-                out_dx = out_dx + ((1 - gam_x) * g) * iBR;
-                out_dx = out_dx - ((1 - gam_x) * g) * iBL;
-            }
-            const long p = (long)y * W + x;
-            store_out(gflow + (long)b * 2 * HW + p, out_dx);
-            store_out(gflow + (long)b * 2 * HW + HW + p, out_dy);
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + NT * j;
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + c * (WH * WW) + 4 * i) = wreg[c][j];
         }
-    };
+    __syncthreads();
 
-    if (!gather_first) {
-        for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
-        __syncthreads();
-
-        float gam_x[PPT], gam_y[PPT];
-        int gbase[PPT], flags[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int idx = tid + NT * k;
-            const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            gam_x[k] = gam_y[k] = 0.0f;
-            gbase[k] = flags[k] = 0;
-            if (!((x < W) && (y < H))) continue;
-            int fl = LIVE;
-            const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
-            const float fx = floorf(xf), fy = floorf(yf);
-            const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
-            gam_y[k] = 1 - (xf - fx);   // c == 1 branch (:169)
-            gam_x[k] = 1 - (yf - fy);   // c == 0 branch (:182)
-            {   // gather corners: clamped with the FLOW dims (:163-166), then to the image
-                const int xL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), xR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
-                const int yT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), yB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
-                const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-                const bool in = (lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH);
-                gbase[k] = in ? lyT * WW + lxL : yT * (int)is.h + xL * (int)is.w;
-                fl |= (in ? G_IN : 0) | (xR != xL ? G_DX : 0) | (yB != yT ? G_DY : 0);
-            }
-            flags[k] = fl;
-            if (abl & 2) continue;
-            // scatter: weights by truncation (:105-106), corners clamped with the INPUT1 dims (:108-114)
-            const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
-            const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
-            const int xL = clampi(ixL, 0, Wi - 1), xR = clampi(ixR, 0, Wi - 1), yT = clampi(iyT, 0, Hi - 1), yB = clampi(iyB, 0, Hi - 1);
-            const int lxL = xL - wx0, lxR = xR - wx0, lyT = yT - wy0, lyB = yB - wy0;
-            if ((lxL >= 0) && (lxR < WW) && (lyT >= 0) && (lyB < WH)) {
-                const int sb = lyT * WWP + lxL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? WWP : 0;
-                {
-                    lds_add_f32x2(a01 + sb, s00 * go[k][0], s00 * go[k][1]);
-                    lds_add_f32x2(a01 + sb + ox, s01 * go[k][0], s01 * go[k][1]);
-                    lds_add_f32x2(a01 + sb + oy, s10 * go[k][0], s10 * go[k][1]);
-                    lds_add_f32x2(a01 + sb + oy + ox, s11 * go[k][0], s11 * go[k][1]);
-                    lds_add_f32(a2 + sb, s00 * go[k][2]);
-                    lds_add_f32(a2 + sb + ox, s01 * go[k][2]);
-                    lds_add_f32(a2 + sb + oy, s10 * go[k][2]);
-                    lds_add_f32(a2 + sb + oy + ox, s11 * go[k][2]);
-                }
+    for (int k = 0; k < PPT; ++k) {
+        const int fl = flags[k], gb = gbase[k];
+        if (!(fl & LIVE)) continue;
+        float out_dx = 0.0f, out_dy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float g = go[k][c];
+            float iTL, iTR, iBL, iBR;
+            if (abl & 4) { iTL = iTR = iBL = iBR = g; }
+            else if (fl & G_IN) {
+                const float *wc = iwin + c * (WH * WW);
+                const int ox = (fl & G_DX) ? 1 : 0, oy = (fl & G_DY) ? WW : 0;
+                iTL = wc[gb]; iTR = wc[gb + ox]; iBL = wc[gb + oy]; iBR = wc[gb + oy + ox];
             } else {
-                const int sb = yT * Wi + xL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? Wi : 0;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float *G = gimg + ((long)b * C + c) * HWi + sb;
-                    unsafeAtomicAdd(G, s00 * go[k][c]);
-                    unsafeAtomicAdd(G + ox, s01 * go[k][c]);
-                    unsafeAtomicAdd(G + oy, s10 * go[k][c]);
-                    unsafeAtomicAdd(G + oy + ox, s11 * go[k][c]);
-                }
+                const float *I = img + (long)b * is.b + (long)c * is.c;
+                const int ox = (fl & G_DX) ? (int)is.w : 0, oy = (fl & G_DY) ? (int)is.h : 0;
+                iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
             }
+            out_dy = out_dy + (gam_y[k] * g) * iBL;       // (:172-177)
+            out_dy = out_dy - (gam_y[k] * g) * iTL;
+            out_dy = out_dy + ((1 - gam_y[k]) * g) * iBR;
+            out_dy = out_dy - ((1 - gam_y[k]) * g) * iTR;
+            out_dx = out_dx + (gam_x[k] * g) * iTR;       // (:185-190)
+            out_dx = out_dx - (gam_x[k] * g) * iTL;
+            out_dx = out_dx + ((1 - gam_x[k]) * g) * iBR;
+            out_dx = out_dx - ((1 - gam_x[k]) * g) * iBL;
         }
-        __syncthreads();
-
-        // the three image windows are requested now: their latency passes under the flush
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int i = tid + NT * j;
-                const int ly = i / (WW / 4), lx = (i - ly * (WW / 4)) * 4;
-                const int gy = wy0 + ly, gx = wx0 + lx;
-                f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-                if (i < WH * (WW / 4) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
-                    v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
-                wreg[c][j] = v;
-            }
-        if (!(abl & 1)) {
-            int ly = tid / WW, lx = tid - ly * WW;
-#pragma unroll 2
-            for (int i = tid; i < WH * WW; i += NT) {
-                const int gx = wx0 + lx, gy = wy0 + ly;
-                const int cell = ly * WWP + lx;
-                float v0, v1, v2;
-                {
-                    const unsigned long long u = a01[cell];
-                    v0 = __uint_as_float((unsigned)u); v1 = __uint_as_float((unsigned)(u >> 32)); v2 = a2[cell];
-                }
-                if (gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) {
-                    float *G = gimg + (long)b * C * HWi + gy * Wi + gx;
-                    if (v0 != 0.0f) unsafeAtomicAdd(G, v0);
-                    if (v1 != 0.0f) unsafeAtomicAdd(G + HWi, v1);
-                    if (v2 != 0.0f) unsafeAtomicAdd(G + 2 * HWi, v2);
-                }
-                ly += NT / WW; lx += NT % WW;
-                if (lx >= WW) { lx -= WW; ++ly; }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int i = tid + NT * j;
-                if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + c * (WH * WW) + 4 * i) = wreg[c][j];
-            }
-        __syncthreads();
-
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int fl = flags[k], gb = gbase[k];
-            if (!(fl & LIVE)) continue;
-            float out_dx = 0.0f, out_dy = 0.0f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float g = go[k][c];
-                float iTL, iTR, iBL, iBR;
-                if (abl & 4) { iTL = iTR = iBL = iBR = g; }
-                else if (fl & G_IN) {
-                    const float *wc = iwin + c * (WH * WW);
-                    const int ox = (fl & G_DX) ? 1 : 0, oy = (fl & G_DY) ? WW : 0;
-                    iTL = wc[gb]; iTR = wc[gb + ox]; iBL = wc[gb + oy]; iBR = wc[gb + oy + ox];
-                } else {
-                    const float *I = img + (long)b * is.b + (long)c * is.c;
-                    const int ox = (fl & G_DX) ? (int)is.w : 0, oy = (fl & G_DY) ? (int)is.h : 0;
-                    iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
-                }
-                out_dy = out_dy + (gam_y[k] * g) * iBL;       // (:172-177)
-                out_dy = out_dy - (gam_y[k] * g) * iTL;
-                out_dy = out_dy + ((1 - gam_y[k]) * g) * iBR;
-                out_dy = out_dy - ((1 - gam_y[k]) * g) * iTR;
-                out_dx = out_dx + (gam_x[k] * g) * iTR;       // (:185-190)
-                out_dx = out_dx - (gam_x[k] * g) * iTL;
-                out_dx = out_dx + ((1 - gam_x[k]) * g) * iBR;
-                out_dx = out_dx - ((1 - gam_x[k]) * g) * iBL;
-            }
-            const int idx = tid + NT * k;
-            const int x = X0 + idx % TW, y = Y0 + idx / TW;
-            const long p = (long)y * W + x;
-            store_out(gflow + (long)b * 2 * HW + p, out_dx);
-            store_out(gflow + (long)b * 2 * HW + HW + p, out_dy);
-        }
-    } else {
-        win_load();
-        win_write();
-        __syncthreads();
-        gather();
-        __syncthreads();
-        zero();
-        __syncthreads();
-        scatter();
-        __syncthreads();
-        flush();
+        const int idx = tid + NT * k;
+        const int x = X0 + idx % TW, y = Y0 + idx / TW;
+        const long p = (long)y * W + x;
+        store_out(gflow + (long)b * 2 * HW + p, out_dx);
+        store_out(gflow + (long)b * 2 * HW + HW + p, out_dy);
     }
 }
 
@@ -1445,16 +1377,14 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
     } while (0)
         // bits 12-13: tile height (profiling: 1 = 48, 2 = 32, 3 = 64), 0 = automatic; bits 14-15: accumulation window
         // (profiling: 1 = fp64 cells 48 x 64 +- 12, 2 = fp64 cells 32 x 64 +- 16, 3 = fp64 cells 48 x 64 +- 16, one workgroup per CU)
-#define FN2_RC3(ORD)                                                                                                      \
+#define FN2_RC3()                                                                                                         \
     do {                                                                                                               \
         const int tiles_y = (H + 31) / 32;                                                                             \
-        hipLaunchKernelGGL((resample_bwd_tiled_c3<32, TW, 16, 1024, ORD>), dim3((unsigned)((long)B * tiles_x * tiles_y)), \
+        hipLaunchKernelGGL((resample_bwd_tiled_c3<32, TW, 16, 1024>), dim3((unsigned)((long)B * tiles_x * tiles_y)), \
                            dim3(1024), 0, s, img, is, flow, grad_out, grad_img, grad_flow, Hi, Wi, H, W, tiles_x,      \
                            tiles_y, abl);                                                                              \
     } while (0)
         switch ((bilinear >> 12) & 15) {
-        case 13: if (C == 3) FN2_RC3(0); else FN2_RB(32, 16, 8, 1); break;   // profiling: every workgroup scatters first
-        case 14: if (C == 3) FN2_RC3(1); else FN2_RB(32, 16, 8, 1); break;   // profiling: order alternates with i / 256
         case 1: FN2_RB(48, 16, 8, 0); break;
         case 2: FN2_RB(32, 16, 8, 0); break;
         case 3: FN2_RB(64, 16, 8, 0); break;
@@ -1469,7 +1399,7 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
         // C == 3 (FlowNet2's only use): the three channels in one scatter, workgroup order alternating with i / 8 -- 8 x 3 x 384 x 512,
         // white-noise flow 51.0 us, smooth flow 37.7.  Other C: one channel at a time, 32-row tiles with fp64 cells (74 KB of LDS, two
         // workgroups per CU; selector 8): 54.2 / 38.6 us against 57.2-59.8 / 44.5 for the 48 x 64 fp32 tiles of round 3 (selector 10)
-        default: if (C == 3) FN2_RC3(2); else FN2_RB(32, 16, 8, 1); break;
+        default: if (C == 3) FN2_RC3(); else FN2_RB(32, 16, 8, 1); break;
         }
 #undef FN2_RB
 #undef FN2_RC3

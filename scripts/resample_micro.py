@@ -26,7 +26,8 @@ def timeit(fn, n=20):
     torch.cuda.synchronize()
     ts = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
     return ts[len(ts) // 2]
-for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth)):
+shift = smooth.clone(); shift[:, 0] += 25.0; shift[:, 1] -= 18.0
+for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth), ("the smooth flow + a translation of (25, -18) px", shift)):
     print(name)
     for flags, lab in ((1, "fwd (default: 3 windows resident, 32x64)"), (1 | 0x1000, "fwd per channel 48x64"), (1 | 0x2000, "fwd per channel 32x64"), (1 | 0x3000, "fwd 96x64, 3 windows resident"), (1 | 0x4000, "fwd 48x64, 4 px per thread"), (1 | 0x8000, "fwd 64x64, 4 px per thread"), (1 | 0x100, "fwd untiled")):
         t = timeit(lambda: lib.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags & ~0xff, st))
@@ -37,7 +38,7 @@ for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth
     ref = None
     for flags, lab in ((1, "bwd (default: 3 channels at once)"), (1 | 0xA000, "bwd tiled, round-3 choice"), (1 | 0x1000, "bwd tiled 48x64"), (1 | 0x2000, "bwd tiled 32x64"), (1 | 0x3000, "bwd tiled 64x64"),
                        (1 | 0x5000, "bwd 48x64 +-12 f32 CAS"), (1 | 0x4000, "bwd 48x64 +-12 fp64 cells"), (1 | 0x8000, "bwd 32x64 +-16 fp64 cells"),
-                       (1 | 0xD000, "3ch, every workgroup scatters first"), (1 | 0xE000, "3ch, order alternates with i/256"), (1 | 0xD000 | 0x200, "3ch scatter first, no flush"), (1 | 0xD000 | 0x400, "3ch scatter first, no scatter"), (1 | 0xD000 | 0xE00, "3ch scatter first, none of them"), (1 | 0xC000, "bwd 48x64 +-16 fp64, 1 WG/CU"), (1 | 0x9000, "bwd 48x64 +-16 f32, 1 WG/CU"),
+                       (1 | 0x200, "3ch, no flush"), (1 | 0x400, "3ch, no scatter"), (1 | 0xE00, "3ch, none of them"), (1 | 0xC000, "bwd 48x64 +-16 fp64, 1 WG/CU"), (1 | 0x9000, "bwd 48x64 +-16 f32, 1 WG/CU"),
                        (1 | 0x6000, "bwd 96x64 +-16 f32, 1 WG/CU"), (1 | 0x7000, "bwd 96x64 +-16 fp64, 1 WG/CU"),
                        (1 | 0x4000 | 0x200, "fp64 48x64+-12, no flush"), (1 | 0x4000 | 0x400, "fp64 48x64+-12, no scatter"),
                        (1 | 0x8200, "fp64 32x64, no flush"), (1 | 0x8400, "fp64 32x64, no scatter"), (1 | 0x8800, "fp64 32x64, no img gather"),
