@@ -987,16 +987,22 @@ __device__ __forceinline__ void c3_add_pixel(unsigned long long *a01, float *a2,
         lds_add_f32(a2 + sb + oy, s10 * g2);
         lds_add_f32(a2 + sb + oy + ox, s11 * g2);
     } else {
+        // corners that clamping merged into one cell are added once (their weights summed first: the reference issues them as
+        // separate atomics in no particular order)
         typedef __attribute__((address_space(3))) float lds_float;
         lds_float *p01 = (lds_float *)a01, *p2 = (lds_float *)a2;
-        const int cell[4] = {sb, sb + ox, sb + oy, sb + oy + ox};
-        const float s[4] = {s00, s01, s10, s11};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_ds_faddf(p01 + 2 * cell[i], s[i] * g0, 0, 0, false);
-            __builtin_amdgcn_ds_faddf(p01 + 2 * cell[i] + 1, s[i] * g1, 0, 0, false);
-            __builtin_amdgcn_ds_faddf(p2 + cell[i], s[i] * g2, 0, 0, false);
-        }
+        float a = s00, b = s01, c = s10, d = s11;
+        if (!ox) { a += b; c += d; }
+        if (!oy) { a += c; b += d; }
+        auto add = [&](int cell, float w) {
+            __builtin_amdgcn_ds_faddf(p01 + 2 * cell, w * g0, 0, 0, false);
+            __builtin_amdgcn_ds_faddf(p01 + 2 * cell + 1, w * g1, 0, 0, false);
+            __builtin_amdgcn_ds_faddf(p2 + cell, w * g2, 0, 0, false);
+        };
+        add(sb, a);
+        if (ox) add(sb + ox, b);
+        if (oy) add(sb + oy, c);
+        if (ox && oy) add(sb + oy + ox, d);
     }
 }
 
