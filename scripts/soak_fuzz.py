@@ -64,6 +64,9 @@ while time.time() - t0 < budget:
         img = rng.standard_normal((B, C, H, W)).astype(np.float32)
         flow = (rng.standard_normal((B, 2, H, W)) * float(rng.choice([0.5, 3.0, 12.0]))).astype(np.float32)
         flow.reshape(-1)[rng.integers(0, flow.size, max(1, flow.size // 40))] *= 40.0
+        shifted = rng.random() < 0.35
+        if shifted:   # a translation under it (the backward windows follow the flow; border pile-ups)
+            flow[:, 0] += np.float32(rng.uniform(-70, 70)); flow[:, 1] += np.float32(rng.uniform(-70, 70))
         gout = rng.standard_normal((B, C, H, W)).astype(np.float32)
         lib, P, st = fn2_capi.lib(), (lambda t: __import__("ctypes").c_void_p(t.data_ptr())), None
         import ctypes
@@ -77,7 +80,9 @@ while time.time() - t0 < budget:
         assert lib.fn2_resample2d_backward(P(imd), None, P(fld), P(god), P(gi), P(gf), B, C, H, W, H, W, ks, int(bil), st) == 0
         rgi, rgf = orc.resample_bwd(img, flow, gout, ks, bil)
         s = max(1.0, float(np.abs(rgi).max()), float(np.abs(rgf).max()))
-        e = max(mx(gi.cpu().numpy(), rgi), mx(gf.cpu().numpy(), rgf)) / s; note("resample_bwd", e); assert e <= 2e-5, ("rbwd", B, C, H, W, bil, e)
+        e = max(mx(gi.cpu().numpy(), rgi), mx(gf.cpu().numpy(), rgf)) / s; note("resample_bwd", e)
+        # a translated field piles thousands of terms onto border cells: the oracle's own sequential fp32 sum is that far from fp64
+        assert e <= (1e-4 if shifted else 2e-5), ("rbwd", B, C, H, W, bil, shifted, e)
         pair = rng.standard_normal((B, 2 * C, H, W)).astype(np.float32)
         got = fn2_capi.warp_diff_norm_cat(D(pair), fld, 20.0, bil).cpu().numpy()
         warped = orc.resample_fwd(np.ascontiguousarray(pair[:, C:]), flow, 1, bil)
