@@ -184,7 +184,9 @@ int fn2_resample2d_forward(const float *img, const int64_t *img_strides, const f
  * resample2d_kernel.cu:75-125 backward_input1, :127-198 backward_input2).
  *   grad_out : B x C x H x W contiguous
  *   grad_img : B x C x Hi x Wi contiguous, ACCUMULATED INTO with fp32 atomics -- the caller
- *              zero-fills it first, exactly as the reference's wrapper does (resample2d.py:31)
+ *              zero-fills it first, exactly as the reference's wrapper does (resample2d.py:31).  The order of
+ *              the fp32 additions into a cell is unspecified, as with the reference's atomicAdd: results
+ *              repeat to rounding level, not bit for bit (grad_flow is bit-exact and repeatable)
  *   grad_flow: B x 2 x H x W contiguous, fully written */
 int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const float *flow,
                             const float *grad_out, float *grad_img, float *grad_flow,
