@@ -1537,6 +1537,23 @@ def test_correlation_leakyrelu_cat_backward(dev, oracle):
     assert lib.fn2_correlation_backward_fused(*args(0.1, ws, 64)) == -1
 
 
+def test_correlation_leakyrelu_cat_backward_half(dev):
+    """`fn2_correlation_backward_fused` for half tensors (the mask pass has a half instantiation; the backward is the half
+    matrix-core kernel): identical to masking by hand and calling `fn2_correlation_backward` on the same half tensors."""
+    import fn2_capi
+    for (B, C, H, W, Cr) in ((1, 128, 16, 24, 8), (2, 64, 12, 40, 32)):
+        g = torch.Generator().manual_seed(C + W)
+        a = torch.randn(B, C, H, W, generator=g).half().to(dev)
+        b = torch.randn(B, C, H, W, generator=g).half().to(dev)
+        buf = torch.randn(B, Cr + 441, H, W, generator=g).half().to(dev)      # stands for the forward's concat buffer: only its sign is used
+        gbuf = torch.randn(B, Cr + 441, H, W, generator=g).half().to(dev)
+        g1, g2 = fn2_capi.correlation_backward_fused(a, b, buf, gbuf, Cr, 0.1, 20, 1, 20, 1, 2)
+        out, gs = buf[:, Cr:].float(), gbuf[:, Cr:].float()
+        masked = torch.where(out > 0, gs, gs * 0.1).half().contiguous()       # the same fp32 product, rounded to half once
+        r1, r2 = fn2_capi.correlation_backward(a, b, masked, 20, 1, 20, 1, 2)
+        assert torch.equal(g1, r1) and torch.equal(g2, r2), (B, C, H, W)
+
+
 def test_correlation_half_backward_wide_map_through_module(dev, oracle):
     """Half tensors on a map wider than 64 px: the pybind module widens to fp32 around the column-window kernel instead of taking
     the general one-lane-per-output kernel (9 ms at 8 x 256 x 56 x 128).  Against the oracle on the half-rounded inputs, within
