@@ -357,7 +357,7 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
     enum { LIVE = 1, IN_WIN = 2, DX = 4, DY = 8 };
 
     const int tid = threadIdx.x;
-    int t = blockIdx.x;
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(TH * 16, (2 * TH * 16 + 255) / 256) void resample_f
     __shared__ __attribute__((aligned(16))) float win[2][WH * WW];
     enum { IN_WIN = 2, DX = 4, DY = 8 };
     const int tid = threadIdx.x;
-    int t = blockIdx.x;
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(1024, WPE) void resample_fwd_tiled_all(const float 
     constexpr int NT = 1024, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float win[NC][WH * WW];
     const int tid = threadIdx.x;
-    int t = blockIdx.x;
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
     enum { LIVE = 1, S_IN = 2, G_IN = 4, S_DX = 8, S_DY = 16, G_DX = 32, G_DY = 64 };
 
     const int tid = threadIdx.x;
-    int t = blockIdx.x;
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
     enum { LIVE = 1, G_IN = 4, G_DX = 32, G_DY = 64 };
 
     const int tid = threadIdx.x;
-    int t = blockIdx.x;
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
