@@ -41,4 +41,4 @@ def test_chnorm_golden(oracle, path):
 
 
 def test_golden_present():
-    assert len(golden_files("corr")) >= 5 and len(golden_files("resample")) >= 2 and len(golden_files("chnorm")) >= 3
+    assert len(golden_files("corr")) >= 5 and len(golden_files("resample")) >= 4 and len(golden_files("chnorm")) >= 3

@@ -129,6 +129,25 @@ def test_resample2d(dev, oracle, shape, bilinear):
     assert max_abs(gimg.cpu().numpy(), rimg) <= TOL     # fp32 atomics: order differs from the oracle's
 
 
+@pytest.mark.parametrize("path", golden_files("resample"), ids=os.path.basename)
+def test_resample2d_golden(dev, path):
+    """The HIP kernels against what the REFERENCE's own device code produced (tests/golden/resample_*.npz: resample2d_kernel.cu
+    under the CPU SIMT shim).  The two small fixtures take the untiled kernels; `resample_tiled_*` (make_golden_resample_tiled.py)
+    the tiled three-channel ones -- ragged tiles, a translation of (25, -18) px under the flow, noise, far outliers."""
+    import resample2d_cuda
+    g = np.load(path)
+    img, flow, gout = to_dev(g["img"], dev), to_dev(g["flow"], dev), to_dev(g["gout"], dev)
+    B, C, H, W = g["gout"].shape
+    for bil in (1, 0):
+        out = torch.full((B, C, H, W), float("nan"), device=dev)
+        assert resample2d_cuda.forward(img, flow, out, 1, bool(bil)) == 1
+        assert max_abs(out.cpu().numpy(), g[f"out_bil{bil}"]) <= 1e-6
+    gimg, gflow = torch.zeros_like(img), torch.full_like(flow, float("nan"))
+    assert resample2d_cuda.backward(img, flow, gout, gimg, gflow, 1, True) == 1
+    assert max_abs(gflow.cpu().numpy(), g["gflow"]) <= 1e-6
+    assert max_abs(gimg.cpu().numpy(), g["gimg"]) <= 5e-6 * max(1.0, float(np.abs(g["gimg"]).max()))
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 32), (2, 100, 200), (1, 33, 68), (3, 64, 64), (2, 97, 260), (1, 48, 96)])
 @pytest.mark.parametrize("spread", [0.5, 4.0, 40.0, (4.0, 25.0, -18.0), (0.5, -41.0, 7.0), (2.0, 6.0, 300.0)])
 def test_resample2d_three_channel_kernels(dev, oracle, shape, spread):
