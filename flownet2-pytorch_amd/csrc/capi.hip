@@ -154,13 +154,6 @@ static int corr_backward_impl(const void *in1, const void *in2, const void *grad
     // f16x2: one-time two-term f16 split, gathered G operand (correlation_f16x2_bwd.hip)
     const bool f16x2_ok = corr_bwd_f16x2_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2) &&
                           aligned(in1, 16) && aligned(in2, 16) && aligned(grad_out, 16) && aligned(grad_in1, 16) && aligned(grad_in2, 16);
-#ifdef FN2_DEBUG_BUILD
-    if (debug_variant && algo >= 8000) {   // the half-step pipeline (correlation_f16x2_bwd_pipe.hip: measured, not faster) with profiling switches
-        if (!f16x2_ok || W > 64) return FN2_EUNSUPPORTED;
-        return corr_backward_f16x2_pipe(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),
-                                        441L * H * W, static_cast<float *>(grad_in1), static_cast<float *>(grad_in2), B, C, H, W, algo - 8000, s);
-    }
-#endif
     if (debug_variant && algo >= 6000) {
         if (!f16x2_ok) return FN2_EUNSUPPORTED;
         return corr_backward_f16x2(static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(grad_out),

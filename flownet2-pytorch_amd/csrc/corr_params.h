@@ -39,9 +39,6 @@ void *corr_f16x2_get_debug_buffer();
 bool corr_bwd_f16x2_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
 int corr_backward_f16x2(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
                         int variant, hipStream_t s);
-// half-step software pipeline of the same contraction (correlation_f16x2_bwd_pipe.hip); gout_bs = elements between batch items of gout
-int corr_backward_f16x2_pipe(const float *in1, const float *in2, const float *gout, long gout_bs, float *g1, float *g2,
-                             int B, int C, int H, int W, int variant, hipStream_t s);
 int corr_backward_f16x2_wide(const float *in1, const float *in2, const float *gout, float *g1, float *g2, int B, int C, int H, int W,
                              hipStream_t s);   // W > 64 (correlation_f16x2_bwd_wide.hip)
 

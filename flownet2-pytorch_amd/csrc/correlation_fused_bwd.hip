@@ -9,6 +9,7 @@
 // correlation backward kernels read (correlation_cuda_kernel.cu:150-334, here correlation_f16x2_bwd.hip and its fallbacks).
 // The bits are those of autograd's composition: the same fp32 product s * g, the same kernels afterwards.
 #include "corr_params.h"
+#include <type_traits>
 
 namespace fn2 {
 namespace fb {
@@ -23,8 +24,12 @@ __global__ __launch_bounds__(256) void mask_slice_kernel(const T *__restrict__ g
     const long total = (long)B * n_item;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long n = i / n_item, r = i - n * n_item;
-        const float g = (float)grad[n * gbs + r], o = (float)out[n * obs + r];
-        dst[i] = (T)(o > 0.0f ? g : g * slope);
+        // the test in T (a stored double below the float range must not read as zero), the product in fp32 for half and
+        // float tensors (what leaky_relu_backward computes) and in double for double ones
+        typedef typename std::conditional<std::is_same<T, double>::value, double, float>::type op_t;
+        const T o = out[n * obs + r];
+        const op_t g = (op_t)grad[n * gbs + r];
+        dst[i] = (T)(o > (T)0 ? g : g * (op_t)slope);
     }
 }
 

@@ -12,6 +12,9 @@
 // as the reference's k x k sum up to fp32 summation order), compares with the predictions, optionally writes
 // d(loss)/d(out_i) = grad_scale * w_i / N_i * sign(out_i - t_i), and leaves per-workgroup partial sums that a second tiny
 // kernel adds up in a fixed order (deterministic).
+// norm = 'L2' (losses.py:64-67: the loss of each scale is L2() = mean over pixels of the channel 2-norm, :21-26 -- the same
+// expression as EPE) differs only in the gradient: grad_scale * w_i / (N_i / 2) * (out_i - t_i) / ||out_i - t_i||_2, zero
+// where the norm is zero (torch.norm's backward).
 #include "fn2_common.h"
 
 namespace fn2 {
@@ -20,10 +23,10 @@ constexpr int MS_MAX_SCALES = 6;
 struct MsArgs {
     const float *out[MS_MAX_SCALES];
     float *grad[MS_MAX_SCALES];
-    float gw[MS_MAX_SCALES];       // grad_scale * w_i / N_i
+    float gw[MS_MAX_SCALES];       // grad_scale * w_i / N_i  (norm 2: grad_scale * w_i / (N_i / 2))
     const float *target;
     float *partial;                // [nblocks][2 * ns]
-    int B, H, W, s0, ns, kmax, bx, by, vec4;
+    int B, H, W, s0, ns, kmax, bx, by, vec4, norm;
     float div_flow;
 };
 
@@ -82,8 +85,14 @@ __global__ __launch_bounds__(256) void multiscale_l1_epe_kernel(MsArgs p)
                 l1[i] = fabsf(d0) + fabsf(d1);
                 ep[i] = __fsqrt_rn(d0 * d0 + d1 * d1);
                 if (p.grad[i]) {
-                    p.grad[i][o] = d0 > 0.0f ? p.gw[i] : (d0 < 0.0f ? -p.gw[i] : 0.0f);
-                    p.grad[i][o + plane] = d1 > 0.0f ? p.gw[i] : (d1 < 0.0f ? -p.gw[i] : 0.0f);
+                    if (p.norm == 2) {
+                        const float g = ep[i] > 0.0f ? p.gw[i] / ep[i] : 0.0f;
+                        p.grad[i][o] = g * d0;
+                        p.grad[i][o + plane] = g * d1;
+                    } else {
+                        p.grad[i][o] = d0 > 0.0f ? p.gw[i] : (d0 < 0.0f ? -p.gw[i] : 0.0f);
+                        p.grad[i][o + plane] = d1 > 0.0f ? p.gw[i] : (d1 < 0.0f ? -p.gw[i] : 0.0f);
+                    }
                 }
             }
         }
@@ -149,20 +158,20 @@ extern "C" size_t fn2_multiscale_workspace_bytes(int B, int H, int W, int start_
     return (size_t)B * bx * by * 2 * num_scales * sizeof(float);
 }
 
-extern "C" int fn2_multiscale_l1_epe(const float *const *outputs, const float *target, float *sums, float *const *grads,
-                                     const float *weights, float grad_scale, int B, int H, int W, int start_scale,
-                                     int num_scales, float div_flow, void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int fn2_multiscale_loss(const float *const *outputs, const float *target, float *sums, float *const *grads,
+                                   const float *weights, float grad_scale, int norm, int B, int H, int W, int start_scale,
+                                   int num_scales, float div_flow, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace fn2;
     MsArgs a;
     int rc = ms_geometry(B, H, W, start_scale, num_scales, &a.kmax, &a.bx, &a.by);
     if (rc != FN2_OK) return rc;
-    if (!outputs || !target || !sums || !workspace) return FN2_EINVAL;
+    if (!outputs || !target || !sums || !workspace || (norm != 1 && norm != 2)) return FN2_EINVAL;
     if (workspace_bytes < fn2_multiscale_workspace_bytes(B, H, W, start_scale, num_scales)) return FN2_EINVAL;
     if (!aligned(target, 4) || !aligned(sums, 4) || !aligned(workspace, 4)) return FN2_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     a.target = target; a.partial = static_cast<float *>(workspace);
-    a.B = B; a.H = H; a.W = W; a.s0 = start_scale; a.ns = num_scales; a.div_flow = div_flow;
+    a.B = B; a.H = H; a.W = W; a.s0 = start_scale; a.ns = num_scales; a.div_flow = div_flow; a.norm = norm;
     a.vec4 = (W % 4 == 0) && aligned(target, 16);
     for (int i = 0; i < MS_MAX_SCALES; ++i) { a.out[i] = nullptr; a.grad[i] = nullptr; a.gw[i] = 0.0f; }
     for (int i = 0; i < num_scales; ++i) {
@@ -170,7 +179,7 @@ extern "C" int fn2_multiscale_l1_epe(const float *const *outputs, const float *t
         a.out[i] = outputs[i];
         a.grad[i] = grads ? grads[i] : nullptr;
         const int k = start_scale << i;
-        const double ni = (double)B * 2 * (H / k) * (W / k);
+        const double ni = (double)B * (norm == 2 ? 1 : 2) * (H / k) * (W / k);
         a.gw[i] = (grads && weights && ni > 0) ? (float)((double)grad_scale * (double)weights[i] / ni) : 0.0f;
     }
     const int nblocks = B * a.bx * a.by;
@@ -183,4 +192,12 @@ extern "C" int fn2_multiscale_l1_epe(const float *const *outputs, const float *t
     if (rc != FN2_OK) return rc;
     hipLaunchKernelGGL(multiscale_reduce_kernel, dim3(1), dim3(256), 0, s, a.partial, sums, nblocks, 2 * num_scales);
     return launch_status();
+}
+
+extern "C" int fn2_multiscale_l1_epe(const float *const *outputs, const float *target, float *sums, float *const *grads,
+                                     const float *weights, float grad_scale, int B, int H, int W, int start_scale,
+                                     int num_scales, float div_flow, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return fn2_multiscale_loss(outputs, target, sums, grads, weights, grad_scale, 1, B, H, W, start_scale, num_scales, div_flow,
+                               workspace, workspace_bytes, stream);
 }

@@ -20,7 +20,7 @@ EXPORTS = [
     "fn2_correlation_backward_fused_workspace_bytes", "fn2_correlation_backward_fused",
     "fn2_resample2d_forward", "fn2_resample2d_backward", "fn2_warp_diff_norm_cat",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
-    "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe",
+    "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe", "fn2_multiscale_loss",
 ]
 
 # profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design; exported by
@@ -168,10 +168,11 @@ def warp_diff_norm_cat(pair, flow, div_flow=20.0, bilinear=True):
     return out
 
 
-def multiscale_l1_epe(outputs, target, weights, start_scale=4, div_flow=0.05, want_grads=False, grad_scale=1.0):
-    """SURVEY.md 8f N3 (losses.py:52-86, L1 norm): returns (sums, grads).  sums is a device tensor of 2*n floats --
+def multiscale_l1_epe(outputs, target, weights, start_scale=4, div_flow=0.05, want_grads=False, grad_scale=1.0, norm=1):
+    """SURVEY.md 8f N3 (losses.py:52-86): returns (sums, grads).  sums is a device tensor of 2*n floats --
     sums[i] = sum |out_i - AvgPool_{k_i}(div_flow * target)|, sums[n+i] = sum of the per-pixel channel 2-norms; grads
-    (if requested) are grad_scale * weights[i] / numel(out_i) * sign(out_i - t_i)."""
+    (if requested) are grad_scale * weights[i] / numel(out_i) * sign(out_i - t_i) for norm = 1 (L1) and
+    grad_scale * weights[i] / (numel(out_i) / 2) * (out_i - t_i) / ||out_i - t_i||_2 for norm = 2 (L2, losses.py:64-67)."""
     import torch
     n = len(outputs)
     B, two, H, W = target.shape
@@ -187,7 +188,7 @@ def multiscale_l1_epe(outputs, target, weights, start_scale=4, div_flow=0.05, wa
     gptr = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]) if want_grads else None
     wts = (ctypes.c_float * n)(*[float(w) for w in weights])
     with torch.cuda.device_of(target):
-        check(lib().fn2_multiscale_l1_epe(outs, _p(target), _p(sums), gptr, wts, ctypes.c_float(grad_scale), B, H, W,
-                                          start_scale, n, ctypes.c_float(div_flow), _p(ws), ctypes.c_size_t(wsb),
-                                          _stream(target)), "fn2_multiscale_l1_epe")
+        check(lib().fn2_multiscale_loss(outs, _p(target), _p(sums), gptr, wts, ctypes.c_float(grad_scale), int(norm), B, H, W,
+                                        start_scale, n, ctypes.c_float(div_flow), _p(ws), ctypes.c_size_t(wsb),
+                                        _stream(target)), "fn2_multiscale_loss")
     return sums, grads

@@ -68,6 +68,8 @@ class CorrelationLeakyReLUCatFunction(Function):
 
     @staticmethod
     def forward(ctx, input1, input2, redir, pad_size, kernel_size, max_displacement, stride1, stride2, negative_slope):
+        if not negative_slope > 0 and (input1.requires_grad or input2.requires_grad):
+            raise ValueError("CorrelationLeakyReLUCatFunction differentiates only for negative_slope > 0")
         n_out = ((max_displacement // stride2) * 2 + 1) ** 2
         B, Cr, oH, oW = redir.shape
         buf = redir.new_empty((B, Cr + n_out, oH, oW))
@@ -105,6 +107,11 @@ class CorrelationLeakyReLUCat(nn.Module):
 
     def __init__(self, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, negative_slope=0.1):
         super().__init__()
+        # the backward reads the activation's derivative off the sign of the stored output: only an increasing activation
+        # (slope > 0) keeps that sign (fn2_correlation_backward_fused rejects anything else) -- say so here, not in backward()
+        if not negative_slope > 0:
+            raise ValueError(f"CorrelationLeakyReLUCat needs negative_slope > 0 (got {negative_slope}); for ReLU or a negative "
+                             "slope compose Correlation, the activation and torch.cat")
         self.corr_params = (pad_size, kernel_size, max_displacement, stride1, stride2)
         self.negative_slope = negative_slope
 

@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define FN2_ABI_VERSION 1
+/* 2 (round 5): + fn2_multiscale_loss, fn2_warp_diff_norm_cat_backward.  Additive: every version-1 entry point keeps its
+ * signature and meaning; a caller built against version 1 runs unchanged on a version-2 library. */
+#define FN2_ABI_VERSION 2
 
 /* element types (reference dispatch: AT_DISPATCH_FLOATING_TYPES_AND_HALF for correlation and
  * channelnorm -- correlation_cuda_kernel.cu:386-415, channelnorm_kernel.cu:111,152; float only
@@ -223,6 +225,13 @@ size_t fn2_multiscale_workspace_bytes(int B, int H, int W, int start_scale, int 
 int fn2_multiscale_l1_epe(const float *const *outputs, const float *target, float *sums, float *const *grads,
                           const float *weights, float grad_scale, int B, int H, int W, int start_scale, int num_scales,
                           float div_flow, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the norm of losses.py:62-67 selectable: norm = 1 is fn2_multiscale_l1_epe; norm = 2 is MultiScale(norm='L2'),
+ * whose per-scale loss L2() (losses.py:21-26) is the expression of EPE (:12) -- `sums` is unchanged (the loss is then
+ * sum_i w_i * sums[num_scales + i] / (B*H_i*W_i)) and grads[i] = grad_scale * weights[i] / (B*H_i*W_i) *
+ * (out_i - t_i) / ||out_i - t_i||_2 per pixel, 0 where that norm is 0 (torch.norm's backward). */
+int fn2_multiscale_loss(const float *const *outputs, const float *target, float *sums, float *const *grads,
+                        const float *weights, float grad_scale, int norm, int B, int H, int W, int start_scale, int num_scales,
+                        float div_flow, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces channelnorm_kernel_forward (channelnorm_kernel.cuh:5-8; kernel
  * channelnorm_kernel.cu:18-60).  in : B x C x H x W contiguous, out : B x 1 x H x W contiguous.

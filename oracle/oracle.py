@@ -166,3 +166,25 @@ def multiscale_l1_epe_sums(outputs, target, start_scale=4, div_flow=0.05):
         l1.append(np.abs(d).sum())
         epe.append(np.sqrt((d * d).sum(axis=1)).sum())
     return np.array(l1), np.array(epe)
+
+
+def multiscale_grads(outputs, target, weights, norm=1, start_scale=4, div_flow=0.05):
+    """d(sum_i w_i loss_i)/d out_i of the reference's MultiScale (losses.py:74-78) in float64 (test infrastructure):
+    norm 1: w_i / N_i * sign(out_i - t_i) (L1, :17); norm 2: w_i / (N_i / 2) * (out_i - t_i) / ||out_i - t_i||_2 (L2, :25),
+    0 where the norm is 0.  Also returns |out_i - t_i| so that a test can leave sign flips at rounding level aside."""
+    t = (np.float32(div_flow) * target.astype(np.float32)).astype(np.float32)
+    grads, absd = [], []
+    for i, o in enumerate(outputs):
+        k = start_scale << i
+        B, _, H, W = t.shape
+        Hi, Wi = H // k, W // k
+        ti = t[:, :, :Hi * k, :Wi * k].reshape(B, 2, Hi, k, Wi, k).astype(np.float64).mean(axis=(3, 5))
+        d = o.astype(np.float64) - ti
+        if norm == 1:
+            g = weights[i] / max(d.size, 1) * np.sign(d)
+        else:
+            r = np.sqrt((d * d).sum(axis=1, keepdims=True))
+            g = weights[i] / max(d.size // 2, 1) * np.where(r > 0, d / np.where(r > 0, r, 1.0), 0.0)
+        grads.append(g)
+        absd.append(np.abs(d))
+    return grads, absd

@@ -122,28 +122,7 @@ if a.bwd:
             t0 = int(st[:, :7][st[:, :7] > 0].min())
             for w in range(8):
                 print("   wave", w, [int(v) - t0 if v > 0 else None for v in st[w, :7]])
-        if algo >= 8000 and ((algo - 8000) & 64):   # half-step pipeline: timeline of each workgroup's first task
-            torch.cuda.synchronize()
-            st = dbg.cpu().view(256, 2, 16)
-            base = st[:, :, 0].min(dim=1, keepdim=True).values.unsqueeze(2)
-            zero = st == 0
-            st = (st - base).double()
-            st[zero] = -1
-            names = ["start", "prologue issued/landed", "barrier after step 1", "s2 DMA issued", "s2 MFMAs+gather done | X(3) written, X(4) requested", "s2 DMA landed",
-                     "s2 barrier", "s3 DMA issued", "s3 MFMAs+gather done | X(4) written, X(5) requested", "s3 DMA landed", "s3 barrier", "-", "step loop done", "rows stored",
-                     "next X(0) written (Q')", "end"]
-            m = lambda role, i: float(st[:, role, i][st[:, role, i] >= 0].mean()) if (st[:, role, i] >= 0).any() else float("nan")
-            print("   SUMMARY %d: step2 %.0f step3 %.0f | staging s2: dma-issue %.0f xwrite+xreq %.0f dma-wait %.0f barrier %.0f | matrix s2 work %.0f wait %.0f, s3 work %.0f wait %.0f | loop/12 %.0f epilogue %.0f total %.0f" % (
-                algo, m(0, 6) - m(0, 2), m(0, 10) - m(0, 6), m(0, 3) - m(0, 2), m(0, 4) - m(0, 3), m(0, 5) - m(0, 4), m(0, 6) - m(0, 5),
-                m(1, 4) - m(1, 2), m(1, 6) - m(1, 4), m(1, 8) - m(1, 6), m(1, 10) - m(1, 8), (m(0, 12) - m(0, 10)) / 8, m(0, 14) - m(0, 12), m(0, 15)))
-            for role, rn in ((0, "staging wave 0"), (1, "matrix wave 4")):
-                print("  ", rn)
-                for i, nm in enumerate(names):
-                    v = st[:, role, i]
-                    v = v[v >= 0]
-                    if len(v):
-                        print("     %-32s mean %8.0f  min %8.0f  max %8.0f   (n=%d)" % (nm, float(v.mean()), float(v.min()), float(v.max()), len(v)))
-        elif 6000 <= algo < 8000 and ((algo - 6000) & 64):   # f16x2 backward timeline of each workgroup's first task
+        if 6000 <= algo < 8000 and ((algo - 6000) & 64):   # f16x2 backward timeline of each workgroup's first task
             torch.cuda.synchronize()
             st = dbg.cpu().view(256, 2, 16)
             base = st[:, :, 0].min(dim=1, keepdim=True).values.unsqueeze(2)

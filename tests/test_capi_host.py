@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/flownet2_hip.h but not exported"
     assert sorted(fn2_capi.EXPORTS) == names
-    assert lib.fn2_abi_version() == 1
+    assert lib.fn2_abi_version() == 2
 
 
 def test_product_library_exports_only_the_public_abi():

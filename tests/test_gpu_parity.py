@@ -1023,6 +1023,53 @@ def test_multiscale_l1_epe(dev, shape):
             assert int((diff > 1e-9).sum()) <= max(2, a.numel() // 5000), int((diff > 1e-9).sum())
 
 
+@pytest.mark.parametrize("path", golden_files("multiscale"), ids=lambda p: os.path.basename(p))
+@pytest.mark.parametrize("norm", ["L1", "L2"])
+def test_multiscale_golden(dev, path, norm):
+    """the fused loss against numbers the REFERENCE's losses.py produced (tests/golden/make_golden_losses.py:
+    MultiScale(args, norm)(outputs, target) and autograd through it) -- loss, EPE and every prediction's gradient."""
+    from losses_fused import MultiScale
+    d = np.load(path)
+    outs = [to_dev(d[f"out{i}"], dev).requires_grad_(True) for i in range(5)]
+    loss, epe = MultiScale(None, norm=norm)(tuple(outs), to_dev(d["target"], dev))
+    rl, re = float(d[f"loss_{norm}"]), float(d[f"epe_{norm}"])
+    assert abs(float(loss.detach()) - rl) <= 1e-5 * max(1.0, abs(rl)), (float(loss.detach()), rl)
+    assert abs(float(epe.detach()) - re) <= 1e-5 * max(1.0, abs(re)), (float(epe.detach()), re)
+    loss.backward()
+    for i, o in enumerate(outs):
+        ref = d[f"grad_{norm}_{i}"]
+        diff = np.abs(o.grad.cpu().numpy().astype(np.float64) - ref)
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        if norm == "L1":   # sign() flips where |out - t_i| is at rounding level: allow a handful of such elements
+            assert int((diff > 1e-6 * scale).sum()) <= max(2, ref.size // 5000), int((diff > 1e-6 * scale).sum())
+        else:              # (out - t) / ||out - t||: relative error grows where the norm is at rounding level
+            assert int((diff > 1e-4 * scale).sum()) <= max(2, ref.size // 5000), float(diff.max() / scale)
+            nz = np.abs(ref).sum(axis=1, keepdims=True) == 0
+            assert np.all(o.grad.cpu().numpy()[np.broadcast_to(nz, ref.shape)] == 0) or "zero_diff" not in path
+
+
+def test_multiscale_l2_vs_autograd(dev):
+    """norm = 'L2' (losses.py:64-67) at the training shape against autograd of the reference's statements on the device."""
+    from losses_fused import MultiScale
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 8, 384, 512
+    target = (torch.randn(B, 2, H, W, generator=g) * 5).to(dev)
+    outs = [(torch.randn(B, 2, H // (4 << i), W // (4 << i), generator=g) * 0.3).to(dev) for i in range(5)]
+    weights = [0.32 / 2 ** i for i in range(5)]
+    ot = [o.clone().requires_grad_(True) for o in outs]
+    t = 0.05 * target
+    ref = sum(w * torch.norm(o - torch.nn.functional.avg_pool2d(t, 4 << i, 4 << i), p=2, dim=1).mean() for i, (w, o) in enumerate(zip(weights, ot)))
+    ref.backward()
+    of = [o.clone().requires_grad_(True) for o in outs]
+    loss, epe = MultiScale(None, norm="L2")(tuple(of), target)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert float(loss.detach()) == float(epe.detach())
+    (0.5 * loss).backward()
+    for a, b in zip(of, ot):
+        s = float(b.grad.abs().max())
+        assert float((a.grad - 0.5 * b.grad).abs().max()) <= 2e-5 * s
+
+
 def test_multiscale_l1_double_backward_and_layouts(dev):
     """the fused loss must not rescale its cached gradients in place (second backward over the same graph,
     gradient scalers), must take non-contiguous predictions (channels_last), and accepts a single tensor (eval branch of
@@ -1571,6 +1618,28 @@ def test_correlation_leakyrelu_cat_backward_half(dev):
         masked = torch.where(out > 0, gs, gs * 0.1).half().contiguous()       # the same fp32 product, rounded to half once
         r1, r2 = fn2_capi.correlation_backward(a, b, masked, 20, 1, 20, 1, 2)
         assert torch.equal(g1, r1) and torch.equal(g2, r2), (B, C, H, W)
+
+
+def test_correlation_leakyrelu_cat_backward_double_and_slope_check(dev):
+    """the mask pass computes in double for double tensors (it used to round every gradient through fp32) and tests the
+    stored output in its own type (a value below the float range is still positive); a slope that does not keep the sign is
+    refused where the module is built, not in backward()."""
+    import fn2_capi
+    from networks.correlation_package.correlation import CorrelationLeakyReLUCat
+    B, C, H, W, Cr = 1, 32, 8, 16, 4
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(B, C, H, W, generator=g, dtype=torch.float64).to(dev)
+    b = torch.randn(B, C, H, W, generator=g, dtype=torch.float64).to(dev)
+    buf = torch.randn(B, Cr + 441, H, W, generator=g, dtype=torch.float64).to(dev)
+    buf[0, Cr, 0, :4] = torch.tensor([1e-300, -1e-300, 1e-60, -1e-60], dtype=torch.float64)
+    gbuf = torch.randn(B, Cr + 441, H, W, generator=g, dtype=torch.float64).to(dev)
+    g1, g2 = fn2_capi.correlation_backward_fused(a, b, buf, gbuf, Cr, 0.1, 20, 1, 20, 1, 2)
+    masked = torch.where(buf[:, Cr:] > 0, gbuf[:, Cr:], gbuf[:, Cr:] * float(np.float32(0.1))).contiguous()
+    r1, r2 = fn2_capi.correlation_backward(a, b, masked, 20, 1, 20, 1, 2)
+    assert torch.equal(g1, r1) and torch.equal(g2, r2)
+    for slope in (0.0, -0.1):
+        with pytest.raises(ValueError):
+            CorrelationLeakyReLUCat(20, 1, 20, 1, 2, negative_slope=slope)
 
 
 def test_correlation_half_backward_wide_map_through_module(dev, oracle):
