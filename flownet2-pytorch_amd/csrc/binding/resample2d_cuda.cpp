@@ -94,11 +94,45 @@ int warp_diff_norm_cat_hip(at::Tensor &pair, at::Tensor &flow, at::Tensor &outpu
     return 1;
 }
 
+// Backward of warp_diff_norm_cat (fn2_warp_diff_norm_cat_backward).  gradPair: an empty tensor (numel 0) = not wanted.
+int warp_diff_norm_cat_backward_hip(at::Tensor &pair, at::Tensor &flow, at::Tensor &output, at::Tensor &gradOutput,
+                                    at::Tensor &gradPair, at::Tensor &gradFlow, double div_flow, bool bilinear)
+{
+    const char *op = "resample2d_cuda.warp_diff_norm_cat_backward";
+    check_gpu(pair, op, "pair");
+    check_same(pair, flow, op, "flow");
+    check_same(pair, output, op, "output");
+    check_same(pair, gradOutput, op, "gradOutput");
+    check_same(pair, gradFlow, op, "gradFlow");
+    TORCH_CHECK(pair.scalar_type() == at::kFloat, op, ": float32 tensors expected, got ", pair.scalar_type());
+    TORCH_CHECK(pair.dim() == 4 && flow.dim() == 4 && output.dim() == 4 && gradOutput.dim() == 4, op, ": tensors must be 4-D");
+    TORCH_CHECK(pair.size(1) % 2 == 0 && pair.size(1) > 0, op, ": pair must hold two images, got ", pair.sizes());
+    const int B = pair.size(0), C = pair.size(1) / 2, H = pair.size(2), W = pair.size(3);
+    TORCH_CHECK(flow.size(0) == B && flow.size(1) == 2 && flow.size(2) == H && flow.size(3) == W, op, ": flow ", flow.sizes(),
+                " does not match pair ", pair.sizes());
+    TORCH_CHECK(output.sizes() == gradOutput.sizes() && output.size(0) == B && output.size(1) == 3 * C + 3 && output.size(2) == H &&
+                    output.size(3) == W, op, ": output / gradOutput must be [", B, ", ", 3 * C + 3, ", ", H, ", ", W, "]");
+    TORCH_CHECK(pair.is_contiguous() && flow.is_contiguous() && output.is_contiguous(), op, ": pair, flow and output must be contiguous");
+    TORCH_CHECK(gradFlow.sizes() == flow.sizes() && gradFlow.is_contiguous(), op, ": gradFlow must be contiguous and shaped like flow");
+    const bool want_pair = gradPair.defined() && gradPair.numel() > 0;
+    if (want_pair) {
+        check_same(pair, gradPair, op, "gradPair");
+        TORCH_CHECK(gradPair.sizes() == pair.sizes() && gradPair.is_contiguous(), op, ": gradPair must be contiguous and shaped like pair");
+    }
+    c10::DeviceGuard guard(pair.device());
+    at::Tensor go = gradOutput.contiguous();
+    check_rc(fn2_warp_diff_norm_cat_backward(pair.data_ptr<float>(), flow.data_ptr<float>(), output.data_ptr<float>(), go.data_ptr<float>(),
+                                             want_pair ? gradPair.data_ptr<float>() : nullptr, gradFlow.data_ptr<float>(), (float)div_flow,
+                                             B, C, H, W, bilinear ? 1 : 0, current_stream(pair)), op);
+    return 1;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "FlowNet2 Resample2d layer, gfx950 HIP kernels (drop-in for the reference resample2d_cuda)";
     m.def("forward", &resample2d_forward_hip, "Resample2D forward (HIP, gfx950)");
     m.def("backward", &resample2d_backward_hip, "Resample2D backward (HIP, gfx950)");
     m.def("warp_diff_norm_cat", &warp_diff_norm_cat_hip,
-          "cat(pair, warp(second image, flow), flow / div_flow, ||first image - warped||) in one pass (inference)");
+          "cat(pair, warp(second image, flow), flow / div_flow, ||first image - warped||) in one pass");
+    m.def("warp_diff_norm_cat_backward", &warp_diff_norm_cat_backward_hip, "backward of warp_diff_norm_cat in one pass");
 }

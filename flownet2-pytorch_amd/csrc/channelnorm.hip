@@ -65,13 +65,7 @@ __global__ __launch_bounds__(256) void chnorm_fwd_scalar(const T *__restrict__ i
 }
 
 // ---------------------------------------------------------------- backward
-__device__ __forceinline__ float chnorm_grad(float go, float x, float o)
-{
-    // static_cast<float>(gO) * static_cast<float>(x) / (static_cast<float>(out) + 1e-9)  (:93):
-    // float product, double divide, rounded to float.
-    const float prod = go * x;
-    return (float)((double)prod / ((double)o + 1e-9));
-}
+// chnorm_grad(go, x, o): fn2_common.h (shared with the fused warp backward of resample2d.hip)
 
 // contiguous-pixel fast path: gout pixel stride 1 and row stride W (a channel slice of a
 // contiguous NCHW tensor qualifies: only its batch stride differs).

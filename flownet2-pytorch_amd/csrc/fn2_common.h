@@ -51,6 +51,14 @@ template <class V> __device__ __forceinline__ void store_out(V *p, V v)
 #endif
 }
 
+// ChannelNorm's gradient of one element (channelnorm_kernel.cu:93):
+// static_cast<float>(gO) * static_cast<float>(x) / (static_cast<float>(out) + 1e-9) -- float product, double divide, rounded to float.
+__device__ __forceinline__ float chnorm_grad(float go, float x, float o)
+{
+    const float prod = go * x;
+    return (float)((double)prod / ((double)o + 1e-9));
+}
+
 // XCD-aware remap of a 1-D block index: consecutive logical tiles land on the same XCD
 // (hardware dispatches block b to XCD b % 8), so neighbouring tiles share one L2.
 // Bijective for any grid size (cdna guide 5 "XCD swizzle must be bijective").

@@ -715,7 +715,7 @@ __device__ __forceinline__ float middle_of_four(const float v[4])
     const float m1 = fmaxf(a, c), m2 = fminf(b, d);
     return fabsf(m1 - m2) < 8.0f ? 0.5f * (m1 + m2) : 0.0f;
 }
-__device__ __forceinline__ void tile_window_offset(const TileFlowSample &S, int &offx, int &offy)
+__device__ __forceinline__ void tile_window_offset(const TileFlowSample &S, int &offx, int &offy, int xq = 4)
 {
     float sx[4], sy[4];
 #pragma unroll
@@ -724,7 +724,7 @@ __device__ __forceinline__ void tile_window_offset(const TileFlowSample &S, int 
         sy[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(S.v), 4 + q));
     }
     const float mx = middle_of_four(sx), my = middle_of_four(sy);
-    offx = (fabsf(mx) >= 8.0f && fabsf(mx) < 1.0e6f) ? 4 * (int)rintf(mx * 0.25f) : 0;
+    offx = (fabsf(mx) >= 8.0f && fabsf(mx) < 1.0e6f) ? xq * (int)rintf(mx / (float)xq) : 0;   // xq = 4 or 16: exact divisions
     offy = (fabsf(my) >= 8.0f && fabsf(my) < 1.0e6f) ? (int)rintf(my) : 0;
 }
 
@@ -953,8 +953,8 @@ __global__ __launch_bounds__(NT, WPE) void resample_bwd_tiled(const float *__res
 // gathered for all channels.  Four barriers.  Arithmetic and operation order per output as resample_bwd_tiled with fp32 cells
 // (the kernel of round 3); grad_flow is bit-identical to it.
 // Measured (scripts/resample_micro.py, 8 x 3 x 384 x 512, us; white-noise / smooth flow): loads, barriers and zeroing alone
-// 17 (resample_bwd_tiled: 26), + scatter 14 / 10, + flush 19 / 12: the flush -- 11.5 M device-scope atomics that leave the
-// XCD, bound chip-wide -- is the largest part.  (Half of the workgroups running the gather first, so that their flushes pass
+// 17 (resample_bwd_tiled: 26), + scatter 14 / 10, + flush 19 / 12: the flush is the largest part (why: the atomic-request bound in
+// the kernel's own comment below).  (Half of the workgroups running the gather first, so that their flushes pass
 // under the others' scatters, gained 3 us on the smooth flow and nothing on the white-noise one, and the kernel's time moved by
 // +-3 us with the mere layout of that second path's code: one order, straight-line text.)
 __device__ __forceinline__ void lds_add_f32x2(unsigned long long *a, float v0, float v1)
@@ -1006,48 +1006,102 @@ __device__ __forceinline__ void c3_add_pixel(unsigned long long *a01, float *a2,
     }
 }
 
-template <int TH, int TW, int R, int NT>
-__global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__restrict__ img, ImgStrides is,
-                                                               const float *__restrict__ flow, const float *__restrict__ gout,
-                                                               float *__restrict__ gimg, float *__restrict__ gflow,
-                                                               int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int abl)
+// ---------------------------------------------------------------- backward, three channels: the kernel
+// The scheme described above (all three accumulation windows in LDS, one scatter, one flush, then the image windows and the gather),
+// its inputs in one argument block, and two options (round 5):
+//   FUSED (row N2, models.py:133-138 differentiated): the gradient of the warped image is formed on the fly from the concat
+//     gradient -- g_warped = g_cat[6:9] - g_norm * diff / (norm + 1e-9) (channelnorm_kernel.cu:93), diff = first image - warped
+//     image read back from the forward's concat buffer --, the first image's gradient g_cat[0:3] + g_diff is written on the way, and
+//     the flow gradient gets the flow / div_flow term added;
+//   SCATTER = false when the image pair needs no gradient (it is the network's input): gather only, no LDS atomics, no global
+//     atomics, 73.7 KB of LDS.
+// The window is aligned to 64 bytes in x (tile_window_offset rounds to 16 px here): a flushed row is 6 atomic requests, never 7.
+// What bounds the scattering form (scripts/ubench/atomic_rate.hip, flush_probe.hip): global fp32 atomics on gfx950 are
+// performed outside the XCD whatever their scope -- workgroup and agent scope have ONE encoding, and the rate does not depend
+// on which XCDs share an image -- at ~20.5 G REQUESTS/s chip-wide, a request being the lanes of one instruction that fall into one
+// aligned 64-byte segment (16 consecutive floats cost what a single float costs).  8 x 3 x 384 x 512 with the white-noise flow:
+// 0.59 M flush requests + 0.20 M from the 18 k far pixels = 39 us of atomic-unit time, which cannot start before the first
+// windows are complete (~14 us): 53 us.  Measured and dropped in round 5 (scripts/attic/resample_bwd_fill_farlist.hip.txt,
+// profiles/r05_b_resample_fill_farlist.log): far pixels collected in an LDS list and issued with the two corners of a row in
+// adjacent lanes (half the far requests, but issued in the flush phase instead of trickling out while the atomic unit idles:
+// 59.6 us against 52.7) and the zero fill of grad_input1 folded into the kernel behind claim / completion counters (four
+// dependent memory round trips per workgroup cost more than the 5.7 us fill they replace: 69.0 us against 58.1 with the fill).
+// Arithmetic and operation order per output as resample_bwd_tiled with fp32 cells; grad_flow is bit-identical to it.
+struct C3xArgs {
+    const float *img; ImgStrides is;          // the image that was warped (FUSED: pair + 3 HW, batch stride 6 HW)
+    const float *flow;
+    const float *gout;                        // !FUSED: B x 3 x H x W gradient of the warped image
+    const float *gcat, *pair, *outcat;        // FUSED: B x 12 x H x W concat gradient, B x 6 x H x W images, B x 12 x H x W forward output
+    float *gpair0;                            // FUSED: B x 6 x H x W gradient of the pair (channels 0..2 written here), or null
+    float *gimg; long gimg_bs;                // scatter target, 3 planes of Hi x Wi per item, gimg_bs floats between items
+    float *gflow;
+    int B, Hi, Wi, H, W, tiles_x, tiles_y, abl;
+    float inv_div_flow;
+};
+
+template <bool FUSED>
+__device__ __forceinline__ void c3x_load_go(const C3xArgs &p, int b, long pix, long HW, float go[3], bool write_gpair0)
+{
+    if constexpr (!FUSED) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) go[c] = p.gout[((long)b * 3 + c) * HW + pix];
+    } else {
+        const float gn = p.gcat[((long)b * 12 + 11) * HW + pix], nrm = p.outcat[((long)b * 12 + 11) * HW + pix];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float diff = p.pair[((long)b * 6 + c) * HW + pix] - p.outcat[((long)b * 12 + 6 + c) * HW + pix];   // (models.py:134)
+            const float gd = chnorm_grad(gn, diff, nrm);
+            go[c] = p.gcat[((long)b * 12 + 6 + c) * HW + pix] - gd;
+            if (write_gpair0 && p.gpair0) store_out(p.gpair0 + ((long)b * 6 + c) * HW + pix, p.gcat[((long)b * 12 + c) * HW + pix] + gd);
+        }
+    }
+}
+
+template <int TH, int TW, int R, int NT, bool FUSED, bool SCATTER>
+__global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
 {
     constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT, CELLS = WH * WWP, C = 3;
     constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[CELLS * 12];
-    float *const aw = reinterpret_cast<float *>(smem);                                 // all of it as floats (zeroing)
-    unsigned long long *const a01 = reinterpret_cast<unsigned long long *>(smem);       // [CELLS] (channel 0, channel 1) pairs + [CELLS] floats of channel 2
+    constexpr int WIN_BYTES = SCATTER ? CELLS * 12 : 3 * WH * WW * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WIN_BYTES];
+    float *const aw = reinterpret_cast<float *>(smem);
+    unsigned long long *const a01 = reinterpret_cast<unsigned long long *>(smem);
     float *const a2 = reinterpret_cast<float *>(smem + CELLS * 8);
-    float *const iwin = reinterpret_cast<float *>(smem);                               // the same bytes, at another time: [3][WH * WW]
-    static_assert(3 * WH * WW * 4 <= CELLS * 12, "image windows must fit the accumulation windows' bytes");
+    float *const iwin = reinterpret_cast<float *>(smem);
+    static_assert(3 * WH * WW * 4 <= WIN_BYTES, "image windows must fit the accumulation windows' bytes");
     enum { LIVE = 1, G_IN = 4, G_DX = 32, G_DY = 64 };
 
     const int tid = threadIdx.x;
-    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
     const int X0 = tx * TW, Y0 = ty * TH;
+    const int H = p.H, W = p.W, Hi = p.Hi, Wi = p.Wi;
     const long HW = (long)H * W, HWi = (long)Hi * Wi;
+    const ImgStrides is = p.is;
+    const float *const img = p.img;
+    float *const gimg_b = p.gimg + (long)b * p.gimg_bs;
     TileFlowSample tfs;
-    tile_flow_sample(flow + (long)b * 2 * HW, HW, X0, Y0, TW, TH, H, W, tfs);
+    tile_flow_sample(p.flow + (long)b * 2 * HW, HW, X0, Y0, TW, TH, H, W, tfs);
 
     float fdx[PPT], fdy[PPT], go[PPT][C];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        const long p = ((x < W) && (y < H)) ? (long)y * W + x : 0;
-        fdx[k] = flow[(long)b * 2 * HW + p]; fdy[k] = flow[(long)b * 2 * HW + HW + p];
-#pragma unroll
-        for (int c = 0; c < C; ++c) go[k][c] = gout[((long)b * C + c) * HW + p];
+        const bool live = (x < W) && (y < H);
+        const long pix = live ? (long)y * W + x : 0;
+        fdx[k] = p.flow[(long)b * 2 * HW + pix]; fdy[k] = p.flow[(long)b * 2 * HW + HW + pix];
+        c3x_load_go<FUSED>(p, b, pix, HW, go[k], live);
     }
-    for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
+    if (SCATTER)
+        for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);   // all of that goes out before the wave waits for its flow sample
     int offx, offy;
-    tile_window_offset(tfs, offx, offy);
+    tile_window_offset(tfs, offx, offy, 16);
     const int wx0 = X0 - R + offx, wy0 = Y0 - R + offy;
-    __syncthreads();
+    if (SCATTER) __syncthreads();
 
     float gam_x[PPT], gam_y[PPT];
     int gbase[PPT], flags[PPT];
@@ -1073,7 +1127,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
             fl |= (in ? G_IN : 0) | (xR != xL ? G_DX : 0) | (yB != yT ? G_DY : 0);
         }
         flags[k] = fl;
-        if (abl & 2) continue;
+        if (!SCATTER || (p.abl & 2)) continue;
         // scatter: weights by truncation (:105-106), corners clamped with the INPUT1 dims (:108-114)
         const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
         const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
@@ -1085,10 +1139,11 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
             c3_add_pixel(a01, a2, sb, ox, oy, s00, s01, s10, s11, go[k][0], go[k][1], go[k][2],
                          moved && __popcll(__ballot(moved)) >= 8);
         } else {
+            // far pixel: 12 atomics now, while the atomic unit has nothing else to do (the flushes come later)
             const int sb = yT * Wi + xL, ox = (xR != xL) ? 1 : 0, oy = (yB != yT) ? Wi : 0;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                float *G = gimg + ((long)b * C + c) * HWi + sb;
+                float *G = gimg_b + (long)c * HWi + sb;
                 unsafeAtomicAdd(G, s00 * go[k][c]);
                 unsafeAtomicAdd(G + ox, s01 * go[k][c]);
                 unsafeAtomicAdd(G + oy, s10 * go[k][c]);
@@ -1096,7 +1151,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
             }
         }
     }
-    __syncthreads();
+    if (SCATTER) __syncthreads();
 
     // the three image windows are requested now: their latency passes under the flush
     f4 wreg[C][NW];
@@ -1112,28 +1167,30 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
                 v = *reinterpret_cast<const f4 *>(img + (long)b * is.b + (long)c * is.c + (long)gy * is.h + gx);
             wreg[c][j] = v;
         }
-    if (!(abl & 1)) {
-        int ly = tid / WW, lx = tid - ly * WW;
+    if constexpr (SCATTER) {
+        if (!(p.abl & 1)) {
+            int ly = tid / WW, lx = tid - ly * WW;
 #pragma unroll 2
-        for (int i = tid; i < WH * WW; i += NT) {
-            const int gx = wx0 + lx, gy = wy0 + ly;
-            const int cell = ly * WWP + lx;
-            float v0, v1, v2;
-            {
-                const unsigned long long u = a01[cell];
-                v0 = __uint_as_float((unsigned)u); v1 = __uint_as_float((unsigned)(u >> 32)); v2 = a2[cell];
+            for (int i = tid; i < WH * WW; i += NT) {
+                const int gx = wx0 + lx, gy = wy0 + ly;
+                const int cell = ly * WWP + lx;
+                float v0, v1, v2;
+                {
+                    const unsigned long long u = a01[cell];
+                    v0 = __uint_as_float((unsigned)u); v1 = __uint_as_float((unsigned)(u >> 32)); v2 = a2[cell];
+                }
+                if (gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) {
+                    float *G = gimg_b + gy * Wi + gx;
+                    if (v0 != 0.0f) unsafeAtomicAdd(G, v0);
+                    if (v1 != 0.0f) unsafeAtomicAdd(G + HWi, v1);
+                    if (v2 != 0.0f) unsafeAtomicAdd(G + 2 * HWi, v2);
+                }
+                ly += NT / WW; lx += NT % WW;
+                if (lx >= WW) { lx -= WW; ++ly; }
             }
-            if (gx >= 0 && gx < Wi && gy >= 0 && gy < Hi) {
-                float *G = gimg + (long)b * C * HWi + gy * Wi + gx;
-                if (v0 != 0.0f) unsafeAtomicAdd(G, v0);
-                if (v1 != 0.0f) unsafeAtomicAdd(G + HWi, v1);
-                if (v2 != 0.0f) unsafeAtomicAdd(G + 2 * HWi, v2);
-            }
-            ly += NT / WW; lx += NT % WW;
-            if (lx >= WW) { lx -= WW; ++ly; }
         }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -1152,7 +1209,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
         for (int c = 0; c < C; ++c) {
             const float g = go[k][c];
             float iTL, iTR, iBL, iBR;
-            if (abl & 4) { iTL = iTR = iBL = iBR = g; }
+            if (p.abl & 4) { iTL = iTR = iBL = iBR = g; }
             else if (fl & G_IN) {
                 const float *wc = iwin + c * (WH * WW);
                 const int ox = (fl & G_DX) ? 1 : 0, oy = (fl & G_DY) ? WW : 0;
@@ -1173,9 +1230,64 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_tiled_c3(const float *__re
         }
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        const long p = (long)y * W + x;
-        store_out(gflow + (long)b * 2 * HW + p, out_dx);
-        store_out(gflow + (long)b * 2 * HW + HW + p, out_dy);
+        const long pix = (long)y * W + x;
+        if (FUSED) {   // + the gradient through flow / div_flow = flow * (1 / div_flow) (models.py:137)
+            out_dx = out_dx + p.gcat[((long)b * 12 + 9) * HW + pix] * p.inv_div_flow;
+            out_dy = out_dy + p.gcat[((long)b * 12 + 10) * HW + pix] * p.inv_div_flow;
+        }
+        store_out(p.gflow + (long)b * 2 * HW + pix, out_dx);
+        store_out(p.gflow + (long)b * 2 * HW + HW + pix, out_dy);
+    }
+}
+
+// Row N2's backward for shapes the tiled kernel does not take (any C, any size): one lane per pixel, corners from global memory,
+// 4 atomics per (pixel, channel) onto a gradient the host initialised with the concat gradient's slice.
+__global__ __launch_bounds__(256) void warp_diff_norm_cat_bwd_kernel(const float *__restrict__ pair, const float *__restrict__ flow,
+                                                                     const float *__restrict__ outcat, const float *__restrict__ gcat,
+                                                                     float *__restrict__ gpair, float *__restrict__ gflow,
+                                                                     int C, int H, int W, long npix, float inv_div_flow)
+{
+    const long HW = (long)H * W;
+    const int CC = 3 * C + 3;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(g % W);
+        const long row = g / W;
+        const int y = (int)(row % H), b = (int)(row / H);
+        const long pix = (long)y * W + x;
+        const float xf = (float)x + flow[(long)b * 2 * HW + pix], yf = (float)y + flow[(long)b * 2 * HW + HW + pix];
+        const float fx = floorf(xf), fy = floorf(yf);
+        const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
+        const int xL = clampi(ixL, 0, W - 1), xR = clampi(ixR, 0, W - 1), yT = clampi(iyT, 0, H - 1), yB = clampi(iyB, 0, H - 1);
+        const float gam_y = 1 - (xf - fx), gam_x = 1 - (yf - fy);
+        const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
+        const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
+        const float gn = gcat[((long)b * CC + 3 * C + 2) * HW + pix], nrm = outcat[((long)b * CC + 3 * C + 2) * HW + pix];
+        float out_dx = 0.0f, out_dy = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float diff = pair[((long)b * 2 * C + c) * HW + pix] - outcat[((long)b * CC + 2 * C + c) * HW + pix];
+            const float gd = chnorm_grad(gn, diff, nrm);
+            const float go = gcat[((long)b * CC + 2 * C + c) * HW + pix] - gd;
+            const float *I = pair + ((long)b * 2 * C + C + c) * HW;
+            if (gpair) {
+                gpair[((long)b * 2 * C + c) * HW + pix] = gcat[((long)b * CC + c) * HW + pix] + gd;
+                float *G = gpair + ((long)b * 2 * C + C + c) * HW;
+                unsafeAtomicAdd(G + yT * W + xL, s00 * go);
+                unsafeAtomicAdd(G + yT * W + xR, s01 * go);
+                unsafeAtomicAdd(G + yB * W + xL, s10 * go);
+                unsafeAtomicAdd(G + yB * W + xR, s11 * go);
+            }
+            const float iTL = I[yT * W + xL], iTR = I[yT * W + xR], iBL = I[yB * W + xL], iBR = I[yB * W + xR];
+            out_dy = out_dy + (gam_y * go) * iBL;
+            out_dy = out_dy - (gam_y * go) * iTL;
+            out_dy = out_dy + ((1 - gam_y) * go) * iBR;
+            out_dy = out_dy - ((1 - gam_y) * go) * iTR;
+            out_dx = out_dx + (gam_x * go) * iTR;
+            out_dx = out_dx - (gam_x * go) * iTL;
+            out_dx = out_dx + ((1 - gam_x) * go) * iBR;
+            out_dx = out_dx - ((1 - gam_x) * go) * iBL;
+        }
+        gflow[(long)b * 2 * HW + pix] = out_dx + gcat[((long)b * CC + 3 * C) * HW + pix] * inv_div_flow;
+        gflow[(long)b * 2 * HW + HW + pix] = out_dy + gcat[((long)b * CC + 3 * C + 1) * HW + pix] * inv_div_flow;
     }
 }
 
@@ -1249,6 +1361,19 @@ static inline unsigned stream_grid(long nthreads)
 }
 
 } // namespace fn2
+
+// argument block of resample_bwd_c3x for 32 x 64 tiles (the fields of the fused form are set by its caller)
+static fn2::C3xArgs c3x_args(const float *img, fn2::ImgStrides is, const float *flow, float *gimg, long gimg_bs, float *gflow,
+                             int B, int Hi, int Wi, int H, int W, int tiles_x, int abl)
+{
+    fn2::C3xArgs a;
+    a.img = img; a.is = is; a.flow = flow; a.gout = nullptr; a.gcat = a.pair = a.outcat = nullptr; a.gpair0 = nullptr;
+    a.gimg = gimg; a.gimg_bs = gimg_bs; a.gflow = gflow;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = (H + 31) / 32; a.abl = abl;
+    a.inv_div_flow = 0.0f;
+    return a;
+}
+static unsigned c3x_grid(const fn2::C3xArgs &a) { return (unsigned)((long)a.B * a.tiles_x * a.tiles_y); }
 
 // `bilinear`: bit 0 = bilinear (else nearest); bits 8.. = profiling switches that only fn2_debug_resample2d_* set
 // (bit 8: untiled kernels, bits 9-11: backward ablations, bits 12-13: tile height)
@@ -1383,13 +1508,6 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
     } while (0)
         // bits 12-13: tile height (profiling: 1 = 48, 2 = 32, 3 = 64), 0 = automatic; bits 14-15: accumulation window
         // (profiling: 1 = fp64 cells 48 x 64 +- 12, 2 = fp64 cells 32 x 64 +- 16, 3 = fp64 cells 48 x 64 +- 16, one workgroup per CU)
-#define FN2_RC3()                                                                                                         \
-    do {                                                                                                               \
-        const int tiles_y = (H + 31) / 32;                                                                             \
-        hipLaunchKernelGGL((resample_bwd_tiled_c3<32, TW, 16, 1024>), dim3((unsigned)((long)B * tiles_x * tiles_y)), \
-                           dim3(1024), 0, s, img, is, flow, grad_out, grad_img, grad_flow, Hi, Wi, H, W, tiles_x,      \
-                           tiles_y, abl);                                                                              \
-    } while (0)
         switch ((bilinear >> 12) & 15) {
         case 1: FN2_RB(48, 16, 8, 0); break;
         case 2: FN2_RB(32, 16, 8, 0); break;
@@ -1405,10 +1523,15 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
         // C == 3 (FlowNet2's only use): the three channels in one scatter, workgroup order alternating with i / 8 -- 8 x 3 x 384 x 512,
         // white-noise flow 51.0 us, smooth flow 37.7.  Other C: one channel at a time, 32-row tiles with fp64 cells (74 KB of LDS, two
         // workgroups per CU; selector 8): 54.2 / 38.6 us against 57.2-59.8 / 44.5 for the 48 x 64 fp32 tiles of round 3 (selector 10)
-        default: if (C == 3) FN2_RC3(); else FN2_RB(32, 16, 8, 1); break;
+        default:
+            if (C == 3) {
+                C3xArgs a = c3x_args(img, is, flow, grad_img, (long)C * Hi * Wi, grad_flow, B, Hi, Wi, H, W, tiles_x, abl);
+                a.gout = grad_out;
+                hipLaunchKernelGGL((resample_bwd_c3x<32, TW, 16, 1024, false, true>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+            } else FN2_RB(32, 16, 8, 1);
+            break;
         }
 #undef FN2_RB
-#undef FN2_RC3
     } else {
         hipLaunchKernelGGL(resample_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, img, is, flow, grad_out,
                            grad_img, grad_flow, C, Hi, Wi, H, W, npix);
@@ -1467,5 +1590,47 @@ extern "C" int fn2_warp_diff_norm_cat(const float *pair, const float *flow, floa
         hipLaunchKernelGGL(warp_diff_norm_cat_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, out, C, H, W,
                            npix, (bilinear & 1) ? 1 : 0, div_flow);
     }
+    return launch_status();
+}
+
+// shapes resample_bwd_c3x takes (the tiled path's conditions, three channels)
+static bool c3x_ok(fn2::ImgStrides is, const float *img, int C, int Hi, int Wi, int H, int W)
+{
+    return C == 3 && (is.w == 1) && (is.h % 4 == 0) && (is.c % 4 == 0) && (is.b % 4 == 0) && fn2::aligned(img, 16) && (Hi == H) &&
+           (Wi == W) && (W % 4 == 0) && (H >= 16) && (W >= 32);
+}
+
+extern "C" int fn2_warp_diff_norm_cat_backward(const float *pair, const float *flow, const float *out_cat, const float *grad_cat,
+                                               float *grad_pair, float *grad_flow, float div_flow, int B, int C, int H, int W,
+                                               int bilinear, void *stream)
+{
+    using namespace fn2;
+    (void)bilinear;   // both reference backward kernels ignore the flag (resample2d_kernel.cu:75-198)
+    if (B < 0 || C < 1 || H < 1 || W < 1 || !(div_flow == div_flow) || div_flow == 0.0f) return FN2_EINVAL;
+    if ((long)B * H * W == 0) return FN2_OK;
+    if (!pair || !flow || !out_cat || !grad_cat || !grad_flow) return FN2_EINVAL;
+    if (!aligned(pair, 4) || !aligned(flow, 4) || !aligned(out_cat, 4) || !aligned(grad_cat, 4) || !aligned(grad_flow, 4) ||
+        (grad_pair && !aligned(grad_pair, 4)))
+        return FN2_EALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    const float inv = 1.0f / div_flow;
+    if (grad_pair) {   // the second image's gradient starts as its slice of the concat gradient (one strided copy), then the scatter adds
+        hipError_t e = hipMemcpy2DAsync(grad_pair + (long)C * HW, 2 * C * HW * sizeof(float), grad_cat + (long)C * HW,
+                                        (3 * C + 3) * HW * sizeof(float), C * HW * sizeof(float), B, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    ImgStrides is;
+    is.b = 2L * C * HW; is.c = HW; is.h = W; is.w = 1;
+    const float *img1 = pair + (long)C * HW;
+    if (c3x_ok(is, img1, C, H, W, H, W)) {
+        C3xArgs a = c3x_args(img1, is, flow, grad_pair ? grad_pair + 3 * HW : nullptr, 6 * HW, grad_flow, B, H, W, H, W, (W + 63) / 64, 0);
+        a.gcat = grad_cat; a.pair = pair; a.outcat = out_cat; a.gpair0 = grad_pair; a.inv_div_flow = inv;
+        if (grad_pair) hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, true, true>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, true, false>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+        return launch_status();
+    }
+    hipLaunchKernelGGL(warp_diff_norm_cat_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, out_cat, grad_cat, grad_pair,
+                       grad_flow, C, H, W, npix, inv);
     return launch_status();
 }

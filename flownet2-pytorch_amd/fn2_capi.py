@@ -19,6 +19,7 @@ EXPORTS = [
     "fn2_correlation_backward", "fn2_correlation_backward_ex",
     "fn2_correlation_backward_fused_workspace_bytes", "fn2_correlation_backward_fused",
     "fn2_resample2d_forward", "fn2_resample2d_backward", "fn2_warp_diff_norm_cat",
+    "fn2_warp_diff_norm_cat_backward",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
     "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe", "fn2_multiscale_loss",
 ]
@@ -166,6 +167,21 @@ def warp_diff_norm_cat(pair, flow, div_flow=20.0, bilinear=True):
         check(lib().fn2_warp_diff_norm_cat(_p(pair), _p(flow), _p(out), ctypes.c_float(div_flow), B, C, H, W,
                                            1 if bilinear else 0, _stream(pair)), "fn2_warp_diff_norm_cat")
     return out
+
+
+def warp_diff_norm_cat_backward(pair, flow, out_cat, grad_cat, div_flow=20.0, bilinear=True, want_grad_pair=True):
+    """fn2_warp_diff_norm_cat_backward through ctypes: returns (grad_pair or None, grad_flow)."""
+    import torch
+    B, C2, H, W = pair.shape
+    C = C2 // 2
+    assert pair.is_contiguous() and flow.is_contiguous() and out_cat.is_contiguous() and grad_cat.is_contiguous()
+    gpair = torch.full_like(pair, float("nan")) if want_grad_pair else None
+    gflow = torch.full_like(flow, float("nan"))
+    with torch.cuda.device_of(pair):
+        check(lib().fn2_warp_diff_norm_cat_backward(_p(pair), _p(flow), _p(out_cat), _p(grad_cat), _p(gpair) if want_grad_pair else None,
+                                                    _p(gflow), ctypes.c_float(div_flow), B, C, H, W, 1 if bilinear else 0,
+                                                    _stream(pair)), "fn2_warp_diff_norm_cat_backward")
+    return gpair, gflow
 
 
 def multiscale_l1_epe(outputs, target, weights, start_scale=4, div_flow=0.05, want_grads=False, grad_scale=1.0, norm=1):

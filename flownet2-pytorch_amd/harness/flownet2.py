@@ -189,11 +189,14 @@ class FlowNet2(nn.Module):
         self.upsample3 = nn.Upsample(scale_factor=4, mode="nearest")
         self.upsample4 = nn.Upsample(scale_factor=4, mode="nearest")
         self.warp_cat = WarpDiffNormCat(div_flow=self.div_flow)
+        self.fused_training = True
 
     def _warp_concat(self, x, flow, resample):
-        """models.py:133-138: cat(x, warped second image, flow / div_flow, ||first image - warped||)."""
+        """models.py:133-138: cat(x, warped second image, flow / div_flow, ||first image - warped||) -- one kernel forward, one
+        kernel backward (WarpDiffNormCat is differentiable since round 5); `fused_training = False` composes the unfused
+        layers under autograd as rounds 1-4 did."""
         dt = x.dtype
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() or self.fused_training:
             return self.warp_cat(x.float(), flow.float()).to(dt)
         warped = resample(x[:, 3:].float(), flow.float())
         norm = self.channelnorm(x[:, :3].float() - warped)

@@ -34,7 +34,8 @@ class Resample2dFunction(Function):
     def backward(ctx, grad_output):
         input1, input2 = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero
+        # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero (reference resample2d.py:31).  (Folding
+        # the fill into the kernel was built and measured in round 5: slower than this fill)
         grad_input1 = torch.zeros_like(input1, memory_format=torch.contiguous_format)
         grad_input2 = torch.empty_like(input2, memory_format=torch.contiguous_format)   # fully written
         resample2d_cuda.backward(input1, input2, grad_output, grad_input1, grad_input2, ctx.kernel_size, ctx.bilinear)
@@ -55,23 +56,47 @@ class Resample2d(nn.Module):
         return Resample2dFunction.apply(input1, input2, self.kernel_size, self.bilinear)
 
 
+class WarpDiffNormCatFunction(Function):
+    """models.py:133-138 as one differentiable op: forward = fn2_warp_diff_norm_cat, backward = fn2_warp_diff_norm_cat_backward
+    (the gradient through resample -> difference -> ChannelNorm -> cat in one kernel; no scatter at all when the image pair
+    needs no gradient, which is the case in FlowNet2, where it is the network's input)."""
+
+    @staticmethod
+    def forward(ctx, x, flow, div_flow, bilinear):
+        x, flow = x.contiguous(), flow.contiguous()
+        b, c2, h, w = x.shape
+        out = x.new_empty((b, c2 + c2 // 2 + 3, h, w))
+        resample2d_cuda.warp_diff_norm_cat(x, flow, out, float(div_flow), bool(bilinear))
+        ctx.save_for_backward(x, flow, out)
+        ctx.div_flow, ctx.bilinear = float(div_flow), bool(bilinear)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, flow, out = ctx.saved_tensors
+        need_x, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_x or need_flow):
+            return None, None, None, None
+        grad_x = torch.empty_like(x) if need_x else x.new_empty(0)
+        grad_flow = torch.empty_like(flow)
+        resample2d_cuda.warp_diff_norm_cat_backward(x, flow, out, grad_out.contiguous(), grad_x, grad_flow, ctx.div_flow, ctx.bilinear)
+        return (grad_x if need_x else None), (grad_flow if need_flow else None), None, None
+
+
 class WarpDiffNormCat(nn.Module):
-    """SURVEY.md 8f N2 (inference): the five statements models.py:133-138 --
+    """the five statements models.py:133-138 --
 
         resampled = Resample2d()(x[:, 3:], flow);  diff = x[:, :3] - resampled;  norm = ChannelNorm()(diff)
         concat = torch.cat((x, resampled, flow / div_flow, norm), dim=1)
 
     -- as one kernel pass (the reference makes x[:, 3:] contiguous, writes and re-reads the warped image, the difference
-    and the norm, then copies all twelve channels again for the concat).  No autograd."""
+    and the norm, then copies all twelve channels again for the concat), differentiable (WarpDiffNormCatFunction): one
+    backward kernel instead of cat / div / ChannelNorm / sub / Resample2d backward passes and their zero fills."""
 
     def __init__(self, div_flow=20.0, bilinear=True):
         super().__init__()
         self.div_flow = div_flow
         self.bilinear = bilinear
 
-    @torch.no_grad()
     def forward(self, x, flow):
-        b, c2, h, w = x.shape
-        out = x.new_empty((b, c2 + c2 // 2 + 3, h, w))
-        resample2d_cuda.warp_diff_norm_cat(x, flow, out, float(self.div_flow), self.bilinear)
-        return out
+        return WarpDiffNormCatFunction.apply(x, flow, float(self.div_flow), self.bilinear)

@@ -207,6 +207,22 @@ int fn2_resample2d_backward(const float *img, const int64_t *img_strides, const 
 int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, float div_flow,
                            int B, int C, int H, int W, int bilinear, void *stream);
 
+/* Row N2, training half: the backward pass of fn2_warp_diff_norm_cat -- what autograd computes through
+ * resample -> difference -> ChannelNorm -> cat (models.py:133-138; resample2d_kernel.cu:75-198, channelnorm_kernel.cu:63-96) -- in
+ * ONE kernel: g_diff = g_norm * diff / (norm + 1e-9) with diff = pair[:, :C] - warped (warped and norm are read back from the
+ * forward's output), g_warped = grad_cat[:, 2C:3C] - g_diff feeds the scatter / gather of the Resample2d backward directly.
+ *   out_cat   : the forward's output, B x (3C+3) x H x W contiguous
+ *   grad_cat  : gradient of that output, contiguous
+ *   grad_pair : NULL (the pair is the network's input: no scatter, no atomics), or B x 2C x H x W contiguous, fully written:
+ *               [:, :C] = grad_cat[:, :C] + g_diff, [:, C:] = grad_cat[:, C:2C] + scatter of g_warped (fp32 atomics, order unspecified)
+ *   grad_flow : B x 2 x H x W contiguous, fully written = Resample2d's flow gradient + grad_cat[:, 3C:3C+2] * (1 / div_flow);
+ *               bit-identical to the composition of the unfused entry points
+ * `bilinear` is accepted and ignored, as by both reference backward kernels.  float32, kernel_size 1.  C = 3 on tileable maps
+ * (H >= 16, W >= 32, W % 4 == 0, 16-byte aligned pair) takes the LDS-window kernel, everything else one lane per pixel. */
+int fn2_warp_diff_norm_cat_backward(const float *pair, const float *flow, const float *out_cat, const float *grad_cat,
+                                    float *grad_pair, float *grad_flow, float div_flow, int B, int C, int H, int W,
+                                    int bilinear, void *stream);
+
 /* "Next" row N3: the training loss of FlowNet2 -- MultiScale with the L1 norm (losses.py:52-86) -- and
  * the EPE metric (losses.py:11-12) in one pass over the target flow instead of five AvgPool2d passes and ~35 launches.
  *   outputs[i] : B x 2 x (H/k_i) x (W/k_i) contiguous device tensors, k_i = start_scale << i, i < num_scales (host array

@@ -251,7 +251,8 @@ def test_flownet2_full_stack_inference(dev):
     with torch.no_grad():
         fused = net(inputs)
     assert tuple(fused.shape) == (2, 2, 128, 192) and torch.isfinite(fused).all()
-    unfused = net(inputs).detach()                    # grad mode: separate modules
+    net.fused_training = False
+    unfused = net(inputs).detach()                    # grad mode, fused_training off: separate modules
     scale = max(float(unfused.abs().max()), 1e-6)
     assert float((fused - unfused).abs().max()) <= 1e-3 * scale
     half = net.half()
@@ -293,7 +294,8 @@ def test_flownet2_hip_layers_vs_torch_stand_ins(dev):
         for p in net.parameters():
             p.mul_(0.5)                                # keeps the random-init stack's flows inside the image
     inputs, _ = synthetic_batch(2, 128, 192, dev, seed=9)
-    hip = net(inputs).detach()                         # grad mode: the separate HIP modules
+    net.fused_training = False
+    hip = net(inputs).detach()                         # grad mode, fused_training off: the separate HIP modules
     saved = (net.flownetc.corr, net.channelnorm, net.resample1, net.resample2, net.resample3, net.resample4)
     net.flownetc.corr, net.channelnorm = TorchCorr(), TorchNorm()
     net.resample1 = net.resample2 = net.resample3 = net.resample4 = TorchResample()
@@ -303,3 +305,35 @@ def test_flownet2_hip_layers_vs_torch_stand_ins(dev):
         net.flownetc.corr, net.channelnorm, net.resample1, net.resample2, net.resample3, net.resample4 = saved
     scale = max(float(ref.abs().max()), 1e-6)
     assert float((hip - ref).abs().max()) <= 1e-3 * scale, (float((hip - ref).abs().max()), scale)
+
+
+@pytest.mark.gpu
+def test_flownet2_trains_through_the_fused_warp(dev):
+    """harness.FlowNet2 in grad mode runs WarpDiffNormCat (one kernel forward, one kernel backward) at its two
+    warp-concat sites (models.py:133-138, :145-150); parameter gradients of one backward pass agree with the same network
+    composed of the separate Resample2d / ChannelNorm modules under autograd (`fused_training = False`)."""
+    from harness.flownet2 import FlowNet2
+    from harness.train import synthetic_batch
+    torch.manual_seed(11)
+    net = FlowNet2().to(dev).train()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    inputs, target = synthetic_batch(2, 128, 192, dev, seed=4)
+    grads = {}
+    for fused in (True, False):
+        net.fused_training = fused
+        net.zero_grad(set_to_none=True)
+        out = net(inputs)
+        (out - target).abs().mean().backward()
+        grads[fused] = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        assert torch.isfinite(out).all()
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 100
+    worst = 0.0
+    for n, g in grads[True].items():
+        ref = grads[False][n]
+        worst = max(worst, float((g - ref).abs().max()) / max(float(ref.abs().max()), 1e-12))
+    # the forward is bit-identical and grad_flow is too; the convolution backward kernels are the same: only the order of
+    # MIOpen's own reductions may differ run to run
+    assert worst <= 1e-3, worst
+    assert any(float(g.abs().max()) > 0 for n, g in grads[True].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp

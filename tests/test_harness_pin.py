@@ -128,6 +128,7 @@ def test_flownet2_matches_reference_class(ref_models):
     ref = ref_models.FlowNet2(SimpleNamespace(rgb_max=255.0, fp16=False)).eval()
     ours = f2.FlowNet2().eval()
     ours.load_state_dict(ref.state_dict())
+    ours.fused_training = False        # the separate (here: plain-torch) layers, not the fused HIP warp
     for net in (ref, ours):
         net.flownetc.corr = TorchCorrelation()
         net.channelnorm = TorchChannelNorm()
