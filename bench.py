@@ -399,6 +399,20 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
             raise RuntimeError(f"FlowNet2C pass failed on a rank: {err!r}" if err is not None else "FlowNet2C pass failed on another rank")
         return t
 
+    if world > 1:
+        # N ranks each running MIOpen's kernel search at once is how a scaling run ends in the watchdog: rank 0 searches first (its
+        # results land in the user find database all ranks of the node share), the others then warm up against that database
+        def warm():
+            tr.train_step(inputs, target)
+            tr.infer(inputs)
+            torch.cuda.synchronize()
+        sync = (lambda: torch.distributed.barrier(device_ids=[dev.index])) if torch.distributed.get_backend() == "nccl" else torch.distributed.barrier
+        if rank == 0:
+            warm()
+        sync()
+        if rank != 0:
+            warm()
+        sync()
     t_train = phase(lambda: time_steps(lambda: tr.train_step(inputs, target), steps, warmup, dev))
     t_fb = phase(lambda: time_steps(fwd_bwd, steps, warmup, dev))
     t_inf = phase(lambda: time_steps(lambda: tr.infer(inputs), steps, warmup, dev))
@@ -579,14 +593,36 @@ def main():
     elapsed = dist_utils.max_over_ranks(elapsed, device=dev)   # the step time is the slowest rank's
     # per-rank consistency check: every rank's own time for its K steps and a checksum of its results
     chk = float(hp.out.double().sum().item() + hp.g1.double().sum().item() + hp.norm.double().sum().item())
-    mine = torch.tensor([own_elapsed, chk, float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+    # two probes of THIS rank's GPU, so that an N-GPU line explains itself (the step time is the slowest rank's): the graded kernel
+    # alone, back to back (operands cache-resident), and a 256 MiB device copy
+    def rank_probes():
+        ts = []
+        for _ in range(9):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(); hp.corr_fwd(); e_.record(); torch.cuda.synchronize()
+            ts.append(s_.elapsed_time(e_) * 1e3)
+        a_, b_ = torch.empty(1 << 26, device=dev), torch.empty(1 << 26, device=dev)
+        b_.copy_(a_)
+        cs = []
+        for _ in range(5):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(); b_.copy_(a_); e_.record(); torch.cuda.synchronize()
+            cs.append(s_.elapsed_time(e_))
+        return sorted(ts)[len(ts) // 2], 2 * a_.numel() * 4 / (min(cs) * 1e-3) / 1e9
+    probe_us, probe_copy = rank_probes()
+    mine = torch.tensor([own_elapsed, chk, float(torch.cuda.current_device()), probe_us, probe_copy], dtype=torch.float64, device=dev)
     if dist is not None:
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
     else:
         allr = [mine]
     per_rank = [{"rank": r, "device": int(t[2].item()), "ms_per_step": round(float(t[0].item()) / args.steps * 1e3, 4),
+                 "image_pairs_per_s": round(CORR["B"] * args.steps / float(t[0].item()), 1),
+                 "corr_fwd_us_warm": round(float(t[3].item()), 1), "copy_GBps_torch": round(float(t[4].item()), 1),
                  "finite": bool(torch.isfinite(t[1]).item())} for r, t in enumerate(allr)]
+    # how far the slowest rank is behind the fastest: `value` = N x pairs / slowest rank's time, so this is the run's scaling
+    # efficiency relative to N copies of its own fastest rank (the driver computes efficiency across runs from `value` itself)
+    rank_balance = round(min(float(t[0].item()) for t in allr) / max(float(t[0].item()) for t in allr), 4)
 
     # Per-kernel durations: the same K steps once more with a HIP event pair around every op on the launch stream
     # (same kernels, same inputs; rocprofv3's per-kernel averages of this command agree).
@@ -768,6 +804,7 @@ def main():
                 480 * 8 * 8 * 33 * 16384),
             "kernels": kernels,
             "per_rank": per_rank,
+            "rank_balance_fastest_over_slowest": rank_balance,
             "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1), **cold,
                     "note": "probes of THIS box: a register-only f16 MFMA stream on every SIMD (first / last five of 40 back-to-back launches; dense "
                             "peak 2500), the streaming copy, and the graded kernel timed alone (operands cache-resident / after a 1 GiB "

@@ -63,6 +63,29 @@ int correlation_forward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::Te
     return 1;
 }
 
+// Half tensors on maps wider than 64 px (Sintel-size conv3): there is no tiled half kernel for that corner (the narrow one holds
+// whole rows of <= 64 px), and the general kernel takes milliseconds.  The fp32 column-window kernel on widened copies is
+// ~25x faster and a superset numerically (exact products of the half operands, fp32 sums; the reference sums in half,
+// correlation_cuda_kernel.cu:229): widen, run, narrow -- three elementwise passes around a 0.3 ms kernel instead of 9 ms.
+// Shared by backward and backward_fused.  `go`: the contiguous half gradient.  false = not this corner (or a shape the
+// fp32 launchers decline): the caller's half path takes it.
+static bool half_wide_backward(const at::Tensor &a, const at::Tensor &b, const at::Tensor &go, at::Tensor &gradInput1, at::Tensor &gradInput2,
+                               int dt, int B, int C, int H, int W, int pad_size, int kernel_size, int max_displacement, int stride1,
+                               int stride2)
+{
+    if (!(dt == FN2_F16 && W > 64 && kernel_size == 1 && stride1 == 1 && stride2 == 2 && pad_size == max_displacement &&
+          max_displacement == 20 && C % 64 == 0 && H % 2 == 0 && W % 8 == 0))
+        return false;
+    at::Tensor a32 = a.to(at::kFloat), b32 = b.to(at::kFloat), go32 = go.to(at::kFloat);
+    at::Tensor g1 = at::empty_like(a32), g2 = at::empty_like(b32);
+    const int rc = fn2_correlation_backward(a32.data_ptr(), b32.data_ptr(), go32.data_ptr(), g1.data_ptr(), g2.data_ptr(), FN2_F32,
+                                            B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, current_stream(a));
+    if (rc != FN2_OK) return false;
+    gradInput1.copy_(g1);
+    gradInput2.copy_(g2);
+    return true;
+}
+
 // correlation_backward_cuda (correlation_cuda.cc:89-167)
 int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor &rInput1, at::Tensor &rInput2,
                              at::Tensor &gradOutput, at::Tensor &gradInput1, at::Tensor &gradInput2, int pad_size,
@@ -90,23 +113,8 @@ int correlation_backward_hip(at::Tensor &input1, at::Tensor &input2, at::Tensor 
     gradInput1.resize_({B, C, H, W});        // correlation_cuda.cc:108-109; fully written, no fill_(0)
     gradInput2.resize_({B, C, H, W});
     TORCH_CHECK(gradInput1.is_contiguous() && gradInput2.is_contiguous(), op, ": gradInputs must be contiguous");
-    // Half tensors on maps wider than 64 px (Sintel-size conv3): there is no tiled half kernel for that corner (the narrow one holds
-    // whole rows of <= 64 px), and the general kernel takes milliseconds.  The fp32 column-window kernel on widened copies is
-    // ~25x faster and a superset numerically (exact products of the half operands, fp32 sums; the reference sums in half,
-    // correlation_cuda_kernel.cu:229): widen, run, narrow -- three elementwise passes around a 0.3 ms kernel instead of 9 ms.
-    if (dt == FN2_F16 && W > 64 && kernel_size == 1 && stride1 == 1 && stride2 == 2 && pad_size == max_displacement &&
-        max_displacement == 20 && C % 64 == 0 && H % 2 == 0 && W % 8 == 0) {
-        at::Tensor a32 = a.to(at::kFloat), b32 = b.to(at::kFloat), go32 = go.to(at::kFloat);
-        at::Tensor g1 = at::empty_like(a32), g2 = at::empty_like(b32);
-        const int rc = fn2_correlation_backward(a32.data_ptr(), b32.data_ptr(), go32.data_ptr(), g1.data_ptr(), g2.data_ptr(), FN2_F32,
-                                                B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
-                                                current_stream(input1));
-        if (rc == FN2_OK) {
-            gradInput1.copy_(g1);
-            gradInput2.copy_(g2);
-            return 1;
-        }   // a shape the fp32 launchers decline: the half path below takes it
-    }
+    if (half_wide_backward(a, b, go, gradInput1, gradInput2, dt, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2))
+        return 1;
     check_rc(fn2_correlation_backward(a.data_ptr(), b.data_ptr(), go.data_ptr(), gradInput1.data_ptr(),
                                       gradInput2.data_ptr(), dt, B, C, H, W, pad_size, kernel_size, max_displacement,
                                       stride1, stride2, current_stream(input1)), op);
@@ -144,6 +152,14 @@ int correlation_backward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::T
     gradInput1.resize_({B, C, H, W});
     gradInput2.resize_({B, C, H, W});
     TORCH_CHECK(gradInput1.is_contiguous() && gradInput2.is_contiguous(), op, ": gradInputs must be contiguous");
+    if (dt == FN2_F16 && W > 64) {
+        // the masked gradient as autograd's leaky_relu_backward forms it for half tensors (fp32 product, rounded to half once), then
+        // the same widened path as `backward`: fused and unfused training give the same gradients on Sintel-size maps too
+        at::Tensor outs = buffer.narrow(1, channel_offset, nOut), gs = gb.narrow(1, channel_offset, nOut).to(at::kFloat);
+        at::Tensor masked = at::where(outs > 0, gs, gs * (float)negative_slope).to(at::kHalf).contiguous();
+        if (half_wide_backward(a, b, masked, gradInput1, gradInput2, dt, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2))
+            return 1;
+    }
     const size_t wsb = fn2_correlation_backward_fused_workspace_bytes(dt, B, H, W, pad_size, kernel_size, max_displacement, stride1, stride2);
     at::Tensor ws = at::empty({(int64_t)B, (int64_t)nOut, (int64_t)oH, (int64_t)oW}, input1.options());   // caching allocator: no synchronisation
     const int64_t off = (int64_t)channel_offset * oH * oW * buffer.element_size(), bs = buffer.size(1) * (int64_t)oH * oW;

@@ -48,3 +48,18 @@ def max_abs(a, b):
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def graded_corr_inputs(fixture):
+    """Inputs of tests/golden/corrgraded_*.npz: not stored, regenerated from the fixture's seed exactly as
+    tests/golden/make_golden_corr_graded.py drew them; the stored checksum tells a different numpy generator from a wrong result."""
+    B, C, H, W = (int(v) for v in fixture["shape"])
+    rng = np.random.default_rng(int(fixture["seed"]))
+    in1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    in2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    gout = rng.standard_normal((B, 441, H, W)).astype(np.float32)
+    in1[0, 3] *= 30.0; in2[0, 7] *= 1e-3
+    chk = np.array([float(np.sum(a.astype(np.float64) * np.arange(1, a.size + 1, dtype=np.float64).reshape(a.shape) % 7.0)) for a in (in1, in2, gout)])
+    if not np.array_equal(chk, fixture["input_checksum"]):
+        pytest.skip("numpy's default_rng draws differ from the ones the fixture was generated with")
+    return in1, in2, gout

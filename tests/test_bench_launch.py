@@ -53,3 +53,32 @@ def test_bench_gpus_2_self_launch():
     assert line.get("dry_run_shared_gpu", False) == share
     if not share:
         assert sorted(p["device"] for p in line["per_rank"]) == [0, 1]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_line_explains_itself():
+    """the 8-rank line before an 8-GPU node shows up -- over RCCL where the box has eight GPUs, else the labelled
+    shared-GPU dry run.  Eight `per_rank` entries, each with its own step time, pairs/s, the graded kernel's warm time and a copy
+    rate of ITS GPU, and the fastest-over-slowest ratio that caps the run's scaling efficiency."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    share = torch.cuda.device_count() < 8
+    if share:
+        env["FN2_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--model", "off"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert len(line["per_rank"]) == 8
+    for p in line["per_rank"]:
+        assert p["finite"] and p["ms_per_step"] > 0 and p["image_pairs_per_s"] > 0 and p["corr_fwd_us_warm"] > 0 and p["copy_GBps_torch"] > 0
+    slowest = max(p["ms_per_step"] for p in line["per_rank"])
+    assert abs(line["ms_per_step"] - slowest) <= 0.25 * slowest + 0.05       # the step time is the slowest rank's (barriers aside)
+    assert 0 < line["rank_balance_fastest_over_slowest"] <= 1.0
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_gpus8_dry_run.json"), "w") as f:
+        f.write(lines[0] + "\n")

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_files, max_abs
+from conftest import golden_files, graded_corr_inputs, max_abs
 
 
 @pytest.mark.parametrize("path", golden_files("corr"), ids=os.path.basename)
@@ -38,6 +38,23 @@ def test_chnorm_golden(oracle, path):
     out = oracle.chnorm_fwd(g["x"])
     assert max_abs(out, g["out"]) == 0.0
     assert max_abs(oracle.chnorm_bwd(g["x"], g["out"], g["gout"]), g["gin"]) == 0.0
+
+
+@pytest.mark.parametrize("path", golden_files("corrgraded"), ids=os.path.basename)
+def test_corr_graded_geometry_golden(oracle, path):
+    """The fixture of the graded geometry (48 x 64 map, FlowNetC's parameters; inputs by seed, the reference's results as sampled
+    planes / channels + float64 sums of all of them): the restated oracle reproduces the reference's device code bit for bit."""
+    g = np.load(path)
+    in1, in2, gout = graded_corr_inputs(g)
+    pad, k, md, s1, s2 = (int(v) for v in g["params"])
+    out = oracle.corr_fwd(in1, in2, pad, k, md, s1, s2)
+    assert max_abs(out[:, g["planes"]], g["out_planes"]) == 0.0
+    o64 = out.astype(np.float64)
+    assert np.array_equal(o64.sum(axis=(0, 2, 3)), g["out_sum"]) and np.array_equal((o64 * o64).sum(axis=(0, 2, 3)), g["out_sumsq"])
+    g1, g2 = oracle.corr_bwd(in1, in2, gout, pad, k, md, s1, s2)
+    assert max_abs(g1[:, g["channels"]], g["g1_channels"]) == 0.0 and max_abs(g2[:, g["channels"]], g["g2_channels"]) == 0.0
+    assert np.array_equal(g1.astype(np.float64).sum(axis=(0, 2, 3)), g["g1_sum"])
+    assert np.array_equal(g2.astype(np.float64).sum(axis=(0, 2, 3)), g["g2_sum"])
 
 
 def test_golden_present():

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_files, max_abs
+from conftest import golden_files, graded_corr_inputs, max_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -380,6 +380,28 @@ def test_correlation_golden(dev, path):
     assert max_abs(res[0], g["out"]) <= TOL
     if has_bwd:
         assert max_abs(res[1], g["g1"]) <= TOL and max_abs(res[2], g["g2"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("corrgraded"), ids=os.path.basename)
+def test_correlation_golden_graded_geometry(dev, path):
+    """the graded f16x2 kernels on their real 48 x 64 task table -- every (row group, neighbour row block) task,
+    ragged displacement ranges at every border -- against the REFERENCE's own device code (tests/golden/make_golden_corr_graded.py:
+    correlation_cuda_kernel.cu under the CPU SIMT shim).  The fixture keeps 32 displacement planes / 8 gradient channels in full and
+    float64 sums of all 441 planes / 64 channels; the inputs are regenerated from its seed."""
+    g = np.load(path)
+    in1, in2, gout = graded_corr_inputs(g)
+    params = tuple(int(v) for v in g["params"])
+    out, g1, g2 = _corr_both(dev, in1, in2, gout, params)
+    out, g1, g2 = out.cpu().numpy(), g1.cpu().numpy(), g2.cpu().numpy()
+    assert max_abs(out[:, g["planes"]], g["out_planes"]) <= 1e-5          # fp32-class sums of 64 products of N(0,1) values (one channel x30)
+    o64 = out.astype(np.float64)
+    n = out.shape[2] * out.shape[3]
+    assert np.max(np.abs(o64.sum(axis=(0, 2, 3)) - g["out_sum"])) <= 1e-5 * n ** 0.5 * 4
+    assert np.max(np.abs((o64 * o64).sum(axis=(0, 2, 3)) - g["out_sumsq"]) / np.maximum(g["out_sumsq"], 1e-30)) <= 1e-5
+    for got, full, ssum, sabs in ((g1, g["g1_channels"], g["g1_sum"], g["g1_abs"]), (g2, g["g2_channels"], g["g2_sum"], g["g2_abs"])):
+        ref_scale = np.abs(full).max(axis=(0, 2, 3), keepdims=True)        # per channel: the two rescaled channels keep their own bar
+        assert np.max(np.abs(got[:, g["channels"]] - full) / np.maximum(ref_scale, 1e-30)) <= 2e-6
+        assert np.max(np.abs(got.astype(np.float64).sum(axis=(0, 2, 3)) - ssum) / np.maximum(sabs, 1e-30)) <= 1e-6
 
 
 MFMA_CASES = [  # B, C, H, W, md  (k=1, s1=1, s2=2, pad=md)
@@ -1710,6 +1732,26 @@ def test_correlation_leakyrelu_cat_backward_half(dev):
         masked = torch.where(out > 0, gs, gs * 0.1).half().contiguous()       # the same fp32 product, rounded to half once
         r1, r2 = fn2_capi.correlation_backward(a, b, masked, 20, 1, 20, 1, 2)
         assert torch.equal(g1, r1) and torch.equal(g2, r2), (B, C, H, W)
+
+
+def test_correlation_half_backward_wide_map_fused_equals_unfused(dev):
+    """`backward_fused` takes the widened column-window path for half tensors on maps wider than 64 px exactly as
+    `backward` does: the fused training path and autograd's three passes give the same half gradients on a Sintel-size map."""
+    import correlation_cuda
+    B, C, H, W, Cr = 1, 64, 16, 72, 8
+    g = torch.Generator().manual_seed(92)
+    a = torch.randn(B, C, H, W, generator=g).half().to(dev)
+    b = torch.randn(B, C, H, W, generator=g).half().to(dev)
+    buf = torch.randn(B, Cr + 441, H, W, generator=g).half().to(dev)
+    gbuf = torch.randn(B, Cr + 441, H, W, generator=g).half().to(dev)
+    e = a.new_empty
+    f1, f2 = e(0), e(0)
+    correlation_cuda.backward_fused(a, b, buf, gbuf, Cr, 0.1, f1, f2, 20, 1, 20, 1, 2)
+    out, gs = buf[:, Cr:].float(), gbuf[:, Cr:].float()
+    masked = torch.where(out > 0, gs, gs * 0.1).half().contiguous()
+    u1, u2 = e(0), e(0)
+    correlation_cuda.backward(a, b, e(0), e(0), masked, u1, u2, 20, 1, 20, 1, 2, 1)
+    assert f1.dtype == torch.float16 and torch.equal(f1, u1) and torch.equal(f2, u2)
 
 
 def test_correlation_leakyrelu_cat_backward_double_and_slope_check(dev):
