@@ -17,6 +17,7 @@
 
 #include "fn2_common.h"
 #include "fn2_debug.h"
+#include "corr_params.h"
 
 namespace fn2 {
 
@@ -1021,7 +1022,9 @@ __device__ __forceinline__ void c3_add_pixel(unsigned long long *a01, float *a2,
 // on which XCDs share an image -- at ~20.5 G REQUESTS/s chip-wide, a request being the lanes of one instruction that fall into one
 // aligned 64-byte segment (16 consecutive floats cost what a single float costs).  8 x 3 x 384 x 512 with the white-noise flow:
 // 0.59 M flush requests + 0.20 M from the 18 k far pixels = 39 us of atomic-unit time, which cannot start before the first
-// windows are complete (~14 us): 53 us.  Measured and dropped in round 5 (scripts/attic/resample_bwd_fill_farlist.hip.txt,
+// windows are complete (timeline, scripts/resample_timeline.py: loads 3 us, then the scatter -- 33 k LDS compare-and-swap pairs per CU
+// at 2.5 per clock: 8-13 us): 50-53 us.  (Delaying the second workgroup of every CU by 2-10 us so that one scatters while the other
+// flushes changes nothing: 53.1-54.7 us, profiles/r05_d_resample_stagger.log.)  Measured and dropped in round 5 (scripts/attic/resample_bwd_fill_farlist.hip.txt,
 // profiles/r05_b_resample_fill_farlist.log): far pixels collected in an LDS list and issued with the two corners of a row in
 // adjacent lanes (half the far requests, but issued in the flush phase instead of trickling out while the atomic unit idles:
 // 59.6 us against 52.7) and the zero fill of grad_input1 folded into the kernel behind claim / completion counters (four
@@ -1037,6 +1040,7 @@ struct C3xArgs {
     float *gflow;
     int B, Hi, Wi, H, W, tiles_x, tiles_y, abl;
     float inv_div_flow;
+    unsigned long long *dbg;                  // profiling (abl & 8): the debug library's stamp buffer (fn2_debug_set_buffer), else null
 };
 
 template <bool FUSED>
@@ -1056,6 +1060,8 @@ __device__ __forceinline__ void c3x_load_go(const C3xArgs &p, int b, long pix, l
         }
     }
 }
+
+__device__ __forceinline__ unsigned t0_tile(unsigned bid, unsigned n) { return xcd_remap(bid, n); }
 
 template <int TH, int TW, int R, int NT, bool FUSED, bool SCATTER>
 __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
@@ -1084,6 +1090,10 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
     float *const gimg_b = p.gimg + (long)b * p.gimg_bs;
     TileFlowSample tfs;
     tile_flow_sample(p.flow + (long)b * 2 * HW, HW, X0, Y0, TW, TH, H, W, tfs);
+    // profiling (abl & 8, debug library only): wall-clock stamps (100 MHz) of the workgroup's phases, dumped into the debug buffer
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) __attribute__((always_inline)) { if ((p.abl & 8) && p.dbg) ts[i] = wall_clock64(); };
+    stamp(0);
 
     float fdx[PPT], fdy[PPT], go[PPT][C];
 #pragma unroll
@@ -1102,6 +1112,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
     tile_window_offset(tfs, offx, offy, 16);
     const int wx0 = X0 - R + offx, wy0 = Y0 - R + offy;
     if (SCATTER) __syncthreads();
+    stamp(1);
 
     float gam_x[PPT], gam_y[PPT];
     int gbase[PPT], flags[PPT];
@@ -1152,6 +1163,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         }
     }
     if (SCATTER) __syncthreads();
+    stamp(2);
 
     // the three image windows are requested now: their latency passes under the flush
     f4 wreg[C][NW];
@@ -1189,6 +1201,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
                 if (lx >= WW) { lx -= WW; ++ly; }
             }
         }
+        stamp(3);      // flush atomics issued (not retired: they return nothing)
         __syncthreads();
     }
 #pragma unroll
@@ -1199,6 +1212,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
             if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(iwin + c * (WH * WW) + 4 * i) = wreg[c][j];
         }
     __syncthreads();
+    stamp(4);
 
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -1237,6 +1251,13 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         }
         store_out(p.gflow + (long)b * 2 * HW + pix, out_dx);
         store_out(p.gflow + (long)b * 2 * HW + HW + pix, out_dy);
+    }
+    if ((p.abl & 8) && p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's atomics and stores have left the CU's queue
+        stamp(5);
+        unsigned long long *d = p.dbg + (long)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) d[i] = ts[i];
+        d[6] = (unsigned long long)t0_tile(blockIdx.x, gridDim.x);
     }
 }
 
@@ -1371,6 +1392,11 @@ static fn2::C3xArgs c3x_args(const float *img, fn2::ImgStrides is, const float *
     a.gimg = gimg; a.gimg_bs = gimg_bs; a.gflow = gflow;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = (H + 31) / 32; a.abl = abl;
     a.inv_div_flow = 0.0f;
+#ifdef FN2_DEBUG_BUILD
+    a.dbg = static_cast<unsigned long long *>(fn2::corr_f16x2_get_debug_buffer());
+#else
+    a.dbg = nullptr;
+#endif
     return a;
 }
 static unsigned c3x_grid(const fn2::C3xArgs &a) { return (unsigned)((long)a.B * a.tiles_x * a.tiles_y); }
@@ -1497,7 +1523,7 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
                           (Hi == H) && (Wi == W) && (W % 4 == 0) && (H >= 16) && (W >= 32) && !(bilinear & 0x100);
     if (tiled_ok) {
         constexpr int TW = 64;
-        const int abl = (bilinear >> 9) & 7;   // bits 9-11 of `bilinear`: profiling switches, 0 from the bindings
+        const int abl = ((bilinear >> 9) & 7) | ((bilinear & 0x10000) ? 8 : 0);   // bits 9-11, 16 of `bilinear`: profiling switches, 0 from the bindings
         const int tiles_x = (W + TW - 1) / TW;
 #define FN2_RB(TH, R, WPE, ACC)                                                                                        \
     do {                                                                                                               \

@@ -391,8 +391,7 @@ def test_correlation_golden_graded_geometry(dev, path):
     g = np.load(path)
     in1, in2, gout = graded_corr_inputs(g)
     params = tuple(int(v) for v in g["params"])
-    out, g1, g2 = _corr_both(dev, in1, in2, gout, params)
-    out, g1, g2 = out.cpu().numpy(), g1.cpu().numpy(), g2.cpu().numpy()
+    out, g1, g2 = (np.asarray(t) if isinstance(t, np.ndarray) else t.cpu().numpy() for t in _corr_both(dev, in1, in2, gout, params))
     assert max_abs(out[:, g["planes"]], g["out_planes"]) <= 1e-5          # fp32-class sums of 64 products of N(0,1) values (one channel x30)
     o64 = out.astype(np.float64)
     n = out.shape[2] * out.shape[3]
