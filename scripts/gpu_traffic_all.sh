@@ -13,7 +13,7 @@ done
 TAG=$TAG python - <<'PY'
 import collections, csv, glob, json, os
 tag = os.environ["TAG"]
-names = {"corr_fwd_f16x2": "corr_fwd", "corr_bwd_f16x2": "corr_bwd", "resample_fwd_tiled": "resample_fwd", "resample_bwd_tiled": "resample_bwd",
+names = {"corr_fwd_f16x2": "corr_fwd", "corr_bwd_f16x2": "corr_bwd", "resample_fwd_tiled": "resample_fwd", "resample_bwd_c3x": "resample_bwd", "resample_bwd_tiled": "resample_bwd",
          "chnorm_fwd_vec": "chnorm_fwd", "chnorm_bwd_vec": "chnorm_bwd"}
 alg = {"corr_fwd": 93683712, "corr_bwd": 144015360, "resample_fwd": 50331648, "resample_bwd": 81788928, "chnorm_fwd": 25165824, "chnorm_bwd": 50331648}
 res = collections.defaultdict(dict)

@@ -81,4 +81,16 @@ def fused_loss():
 
 res["N3_unfused_us"] = timeit(ref_loss)
 res["N3_fused_us"] = timeit(fused_loss)
+# N2, training half (round 5): the backward of models.py:133-138 -- autograd through cat / div / ChannelNorm / sub / Resample2d against
+# the one fused kernel; the image pair without a gradient (FlowNet2's case: it is the network's input) and with one
+gcat = torch.randn(8, 12, 384, 512, generator=g).to(dev)
+for need_x in (False, True):
+    xl, fl = x.clone().requires_grad_(need_x), flow.clone().requires_grad_(True)
+    r = rs(xl[:, 3:], fl)
+    unf = torch.cat((xl, r, fl / 20.0, cn(xl[:, :3] - r)), dim=1)
+    xl2, fl2 = x.clone().requires_grad_(need_x), flow.clone().requires_grad_(True)
+    fus = wd(xl2, fl2)
+    key = "N2_bwd_pair_grad_" if need_x else "N2_bwd_flow_only_"
+    res[key + "unfused_us"] = timeit(lambda: unf.backward(gcat, retain_graph=True))
+    res[key + "fused_us"] = timeit(lambda: fus.backward(gcat, retain_graph=True))
 print(json.dumps(res))
