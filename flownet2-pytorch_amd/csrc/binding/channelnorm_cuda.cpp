@@ -52,8 +52,30 @@ int channelnorm_backward_hip(at::Tensor &input1, at::Tensor &output, at::Tensor 
     return 1;
 }
 
+// forward / backward with their outputs allocated here (the wrappers of this repository; the reference's signatures stay above)
+at::Tensor channelnorm_forward_alloc(at::Tensor &input1, int norm_deg)
+{
+    check_gpu(input1, "channelnorm_cuda.forward_alloc", "input1");
+    TORCH_CHECK(input1.dim() == 4, "channelnorm_cuda.forward_alloc: input1 must be 4-D");
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor output = at::empty({input1.size(0), 1, input1.size(2), input1.size(3)}, input1.options());
+    channelnorm_forward_hip(input1, output, norm_deg);
+    return output;
+}
+
+at::Tensor channelnorm_backward_alloc(at::Tensor &input1, at::Tensor &output, at::Tensor &gradOutput, int norm_deg)
+{
+    check_gpu(input1, "channelnorm_cuda.backward_alloc", "input1");
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor g = at::empty(input1.sizes(), input1.options());
+    channelnorm_backward_hip(input1, output, gradOutput, g, norm_deg);
+    return g;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("forward_alloc", &channelnorm_forward_alloc, "forward returning a freshly allocated output");
+    m.def("backward_alloc", &channelnorm_backward_alloc, "backward returning a freshly allocated gradient");
     m.doc() = "FlowNet2 ChannelNorm layer, gfx950 HIP kernels (drop-in for the reference channelnorm_cuda)";
     m.def("forward", &channelnorm_forward_hip, "Channel norm forward (HIP, gfx950)");
     m.def("backward", &channelnorm_backward_hip, "Channel norm backward (HIP, gfx950)");

@@ -170,8 +170,34 @@ int correlation_backward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::T
     return 1;
 }
 
+// The same two calls for the wrappers of this repository: outputs allocated here (one Python -> C++ transition per op instead of
+// one per tensor; the reference's signatures above stay for code written against them)
+at::Tensor correlation_forward_alloc(at::Tensor &input1, at::Tensor &input2, int pad_size, int kernel_size, int max_displacement,
+                                     int stride1, int stride2, int corr_type_multiply)
+{
+    check_gpu(input1, "correlation_cuda.forward_alloc", "input1");
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor scratch1 = at::empty({0}, input1.options()), scratch2 = at::empty({0}, input1.options()), output = at::empty({0}, input1.options());
+    correlation_forward_hip(input1, input2, scratch1, scratch2, output, pad_size, kernel_size, max_displacement, stride1, stride2, corr_type_multiply);
+    return output;
+}
+
+std::vector<at::Tensor> correlation_backward_alloc(at::Tensor &input1, at::Tensor &input2, at::Tensor &gradOutput, int pad_size,
+                                                   int kernel_size, int max_displacement, int stride1, int stride2, int corr_type_multiply)
+{
+    check_gpu(input1, "correlation_cuda.backward_alloc", "input1");
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor scratch1 = at::empty({0}, input1.options()), scratch2 = at::empty({0}, input1.options());
+    at::Tensor g1 = at::empty({0}, input1.options()), g2 = at::empty({0}, input1.options());
+    correlation_backward_hip(input1, input2, scratch1, scratch2, gradOutput, g1, g2, pad_size, kernel_size, max_displacement, stride1, stride2,
+                             corr_type_multiply);
+    return {g1, g2};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("forward_alloc", &correlation_forward_alloc, "forward returning a freshly allocated output");
+    m.def("backward_alloc", &correlation_backward_alloc, "backward returning freshly allocated gradients");
     m.doc() = "FlowNet2 correlation layer, gfx950 HIP kernels (drop-in for the reference correlation_cuda)";
     m.def("forward", &correlation_forward_hip, "Correlation forward (HIP, gfx950)");
     m.def("backward", &correlation_backward_hip, "Correlation backward (HIP, gfx950)");

@@ -127,8 +127,35 @@ int warp_diff_norm_cat_backward_hip(at::Tensor &pair, at::Tensor &flow, at::Tens
     return 1;
 }
 
+// forward / backward with their outputs allocated here (the wrappers of this repository; the reference's signatures stay above)
+at::Tensor resample2d_forward_alloc(at::Tensor &input1, at::Tensor &input2, int kernel_size, bool bilinear)
+{
+    const char *op = "resample2d_cuda.forward_alloc";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    TORCH_CHECK(input1.dim() == 4 && input2.dim() == 4, op, ": tensors must be 4-D");
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor output = at::empty({input2.size(0), input1.size(1), input2.size(2), input2.size(3)}, input1.options());   // (resample2d.py:16-18)
+    resample2d_forward_hip(input1, input2, output, kernel_size, bilinear);
+    return output;
+}
+
+std::vector<at::Tensor> resample2d_backward_alloc(at::Tensor &input1, at::Tensor &input2, at::Tensor &gradOutput, int kernel_size, bool bilinear)
+{
+    const char *op = "resample2d_cuda.backward_alloc";
+    check_gpu(input1, op, "input1");
+    check_same(input1, input2, op, "input2");
+    c10::DeviceGuard guard(input1.device());
+    at::Tensor g1 = at::zeros(input1.sizes(), input1.options());        // accumulated into: starts at zero (resample2d.py:31)
+    at::Tensor g2 = at::empty(input2.sizes(), input2.options());        // fully written
+    resample2d_backward_hip(input1, input2, gradOutput, g1, g2, kernel_size, bilinear);
+    return {g1, g2};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("forward_alloc", &resample2d_forward_alloc, "forward returning a freshly allocated output");
+    m.def("backward_alloc", &resample2d_backward_alloc, "backward returning freshly allocated gradients");
     m.doc() = "FlowNet2 Resample2d layer, gfx950 HIP kernels (drop-in for the reference resample2d_cuda)";
     m.def("forward", &resample2d_forward_hip, "Resample2D forward (HIP, gfx950)");
     m.def("backward", &resample2d_backward_hip, "Resample2D backward (HIP, gfx950)");

@@ -19,9 +19,7 @@ class ChannelNormFunction(Function):
     @staticmethod
     def forward(ctx, input1, norm_deg=2):
         assert input1.is_contiguous(), "input1 must be contiguous (reference channelnorm.py:9)"
-        batch, _, height, width = input1.size()
-        output = input1.new_empty((batch, 1, height, width))   # fully written by the kernel
-        channelnorm_cuda.forward(input1, output, norm_deg)
+        output = channelnorm_cuda.forward_alloc(input1, norm_deg)   # (B, 1, H, W), allocated on the C++ side, fully written
         ctx.save_for_backward(input1, output)
         ctx.norm_deg = norm_deg
         return output
@@ -29,9 +27,7 @@ class ChannelNormFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         input1, output = ctx.saved_tensors
-        grad_input1 = torch.empty_like(input1)   # fully written by the kernel
-        channelnorm_cuda.backward(input1, output, grad_output, grad_input1, ctx.norm_deg)
-        return grad_input1, None
+        return channelnorm_cuda.backward_alloc(input1, output, grad_output, ctx.norm_deg), None
 
 
 class ChannelNorm(nn.Module):

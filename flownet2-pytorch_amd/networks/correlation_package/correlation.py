@@ -23,21 +23,14 @@ class CorrelationFunction(Function):
                 corr_multiply=1):
         ctx.save_for_backward(input1, input2)
         ctx.corr_params = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
-        with torch.cuda.device_of(input1):
-            # the extension sizes these in place (reference correlation.py:20-22); the two scratch
-            # tensors of the reference ABI stay empty, the HIP kernels need no padded copies
-            scratch1, scratch2, output = input1.new_empty(0), input2.new_empty(0), input1.new_empty(0)
-            correlation_cuda.forward(input1, input2, scratch1, scratch2, output, *ctx.corr_params)
-        return output
+        # correlation_cuda.forward with the reference's three empty tensors (correlation.py:20-22) created and sized on the C++
+        # side: one call, device guard included
+        return correlation_cuda.forward_alloc(input1, input2, *ctx.corr_params)
 
     @staticmethod
     def backward(ctx, grad_output):
         input1, input2 = ctx.saved_tensors
-        with torch.cuda.device_of(input1):
-            scratch1, scratch2 = input1.new_empty(0), input2.new_empty(0)
-            grad_input1, grad_input2 = input1.new_empty(0), input2.new_empty(0)
-            correlation_cuda.backward(input1, input2, scratch1, scratch2, grad_output, grad_input1, grad_input2,
-                                      *ctx.corr_params)
+        grad_input1, grad_input2 = correlation_cuda.backward_alloc(input1, input2, grad_output, *ctx.corr_params)
         return (grad_input1, grad_input2) + (None,) * 6
 
 

@@ -22,23 +22,18 @@ class Resample2dFunction(Function):
         assert input2.is_contiguous(), "flow must be contiguous (reference resample2d.py:10)"
         ctx.save_for_backward(input1, input2)
         ctx.kernel_size, ctx.bilinear = kernel_size, bilinear
-        channels = input1.size(1)
-        batch, _, height, width = input2.size()
         if int(kernel_size) < 1:
             raise ValueError("Resample2d: kernel_size must be >= 1")
-        output = input1.new_empty((batch, channels, height, width))   # fully written by the kernel
-        resample2d_cuda.forward(input1, input2, output, kernel_size, bilinear)
-        return output
+        # output: (B, C_img, H, W) with B, H, W from the flow (reference :16-18), allocated on the C++ side and fully written
+        return resample2d_cuda.forward_alloc(input1, input2, kernel_size, bilinear)
 
     @staticmethod
     def backward(ctx, grad_output):
         input1, input2 = ctx.saved_tensors
-        grad_output = grad_output.contiguous()
-        # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero (reference resample2d.py:31).  (Folding
-        # the fill into the kernel was built and measured in round 5: slower than this fill)
-        grad_input1 = torch.zeros_like(input1, memory_format=torch.contiguous_format)
-        grad_input2 = torch.empty_like(input2, memory_format=torch.contiguous_format)   # fully written
-        resample2d_cuda.backward(input1, input2, grad_output, grad_input1, grad_input2, ctx.kernel_size, ctx.bilinear)
+        # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero (reference resample2d.py:31): zeros and the
+        # contiguous copy of grad_output are made on the C++ side.  (Folding the fill into the kernel was built and measured in round 5:
+        # slower than this fill)
+        grad_input1, grad_input2 = resample2d_cuda.backward_alloc(input1, input2, grad_output, ctx.kernel_size, ctx.bilinear)
         return grad_input1, grad_input2, None, None
 
 

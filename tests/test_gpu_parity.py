@@ -1155,10 +1155,13 @@ def test_multiscale_golden(dev, path, norm):
             # made EXACTLY equal to torch's pooled target (reference gradient 0) may come out +-w/N with this kernel's summation order
             assert int(((diff > 1e-6 * scale) & (ref != 0)).sum()) <= max(2, ref.size // 5000), int((diff > 1e-6 * scale).sum())
             assert float(diff.max()) <= 1.000001 * scale
-        else:              # (out - t) / ||out - t||: relative error grows where the norm is at rounding level
-            assert int((diff > 1e-4 * scale).sum()) <= max(2, ref.size // 5000), float(diff.max() / scale)
-            nz = np.abs(ref).sum(axis=1, keepdims=True) == 0
-            assert np.all(o.grad.cpu().numpy()[np.broadcast_to(nz, ref.shape)] == 0) or "zero_diff" not in path
+        else:
+            # (out - t) / ||out - t||: relative error grows where the norm is at rounding level; pixels the fixture made EXACTLY equal to
+            # torch's pooled target (reference gradient 0: torch.norm's backward at 0) come out as a unit vector x w/N wherever this
+            # kernel's summation order leaves a difference of one ulp
+            zero_px = np.broadcast_to(np.abs(ref).sum(axis=1, keepdims=True) == 0, ref.shape)
+            assert int(((diff > 1e-4 * scale) & ~zero_px).sum()) <= max(2, ref.size // 5000), float(diff.max() / scale)
+            assert float(diff.max()) <= 1.00001 * float(d["weights"][i]) / (ref.size / 2)        # a unit vector x w / (N / 2)
 
 
 def test_multiscale_l2_vs_autograd(dev):
