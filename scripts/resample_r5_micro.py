@@ -1,5 +1,5 @@
-"""Round 5: Resample2d backward -- the round-4 three-channel kernel (selector 11) against resample_bwd_c3x (default; 64-byte
-aligned windows), and row N2's fused backward against autograd through the unfused layers.  8 x 3 x 384 x 512, the SURVEY's white-noise flow, a smooth flow and a translated one."""
+"""Round 5: Resample2d backward (resample_bwd_c3x) with its ablations, and row N2's fused backward against autograd through the
+unfused layers.  (The A/B against the round-4 kernel, the in-kernel zero fill and the far-pixel list: profiles/r05_b_*.log.)  8 x 3 x 384 x 512, the SURVEY's white-noise flow, a smooth flow and a translated one."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
@@ -31,8 +31,7 @@ shift = smooth.clone(); shift[:, 0] += 25.0; shift[:, 1] -= 18.0
 for name, fl in (("white-noise flow N(0,4)+1% outliers", flow.to(dev)), ("smooth flow (sigma ~ 5 px)", smooth), ("the smooth flow + a translation of (25, -18) px", shift)):
     print(name)
     ref = None
-    for flags, lab in ((0xB000, "round-4 kernel (selector 11)"), (0, "round-5 kernel (c3x)"), (0x200, "round-5, no flush"), (0x400, "round-5, no scatter"),
-                       (0xB200, "round-4, no flush"), (0xB400, "round-4, no scatter")):
+    for flags, lab in ((0, "round-5 kernel (c3x)"), (0x200, "round-5, no flush"), (0x400, "round-5, no scatter")):
         call = lambda: dbg.fn2_debug_resample2d_backward(P(img), None, P(fl), P(gout), P(gimg), P(gflow), B, C, H, W, H, W, 1, 1, flags, st)
         def run():
             gimg.zero_(); call()

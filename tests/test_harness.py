@@ -321,19 +321,23 @@ def test_flownet2_trains_through_the_fused_warp(dev):
             p.mul_(0.5)
     inputs, target = synthetic_batch(2, 128, 192, dev, seed=4)
     grads = {}
-    for fused in (True, False):
+    # (two discarded passes first: MIOpen picks its convolution algorithms on the first calls of a shape, and a pass that ran with
+    # other algorithms than the next one differs from it by more than any of the layers under test)
+    for key, fused in (("warm-up", True), ("warm-up 2", False), ("fused", True), ("unfused", False), ("unfused again", False)):
         net.fused_training = fused
         net.zero_grad(set_to_none=True)
         out = net(inputs)
         (out - target).abs().mean().backward()
-        grads[fused] = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        grads[key] = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
         assert torch.isfinite(out).all()
-    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 100
-    worst = 0.0
-    for n, g in grads[True].items():
-        ref = grads[False][n]
-        worst = max(worst, float((g - ref).abs().max()) / max(float(ref.abs().max()), 1e-12))
-    # the forward is bit-identical and grad_flow is too; the convolution backward kernels are the same: only the order of
-    # MIOpen's own reductions may differ run to run
-    assert worst <= 1e-3, worst
+    assert grads["fused"].keys() == grads["unfused"].keys() and len(grads["fused"]) > 100
+
+    def worst(a, b):
+        return max(float((a[n] - b[n]).abs().max()) / max(float(b[n].abs().max()), 1e-12) for n in a)
+    # the forward is bit-identical and so is grad_flow; what differs from run to run is the order of MIOpen's own reductions in the
+    # convolution backward passes (atomics), amplified through five stacked networks: the bar is that run-to-run noise, measured here
+    noise = worst(grads["unfused again"], grads["unfused"])
+    diff = worst(grads["fused"], grads["unfused"])
+    assert diff <= max(1e-3, 4.0 * noise), (diff, noise)
+    grads = {True: grads["fused"]}
     assert any(float(g.abs().max()) > 0 for n, g in grads[True].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp
