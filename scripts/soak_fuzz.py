@@ -59,7 +59,8 @@ while time.time() - t0 < budget:
                 bad = np.abs(gnp - ref) > tol
                 note(name, float(np.max(np.abs(gnp - ref) / tol))); assert not bad.any(), (name, B, C, H, W, float(np.abs(gnp - ref).max()))
     else:
-        B, C, H, W, bil = int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 130)), int(rng.integers(1, 200)), bool(rng.integers(0, 2))
+        B, C, H, W, bil = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 3, 3, 4])), int(rng.integers(1, 130)), int(rng.integers(1, 200)), bool(rng.integers(0, 2))
+        if rng.random() < 0.5: W += (-W) % 4   # tileable widths half of the time
         ks = int(rng.choice([1, 1, 1, 2, 3]))   # window sums (kernel_size > 1) now and then
         img = rng.standard_normal((B, C, H, W)).astype(np.float32)
         flow = (rng.standard_normal((B, 2, H, W)) * float(rng.choice([0.5, 3.0, 12.0]))).astype(np.float32)
@@ -88,5 +89,19 @@ while time.time() - t0 < budget:
         warped = orc.resample_fwd(np.ascontiguousarray(pair[:, C:]), flow, 1, bil)
         refc = np.concatenate((pair, warped, flow * (np.float32(1.0) / np.float32(20.0)), orc.chnorm_fwd(pair[:, :C] - warped)), axis=1)
         e = mx(got, refc); note("warp_diff_norm_cat", e); assert e <= 1e-4, ("n2", B, C, H, W, bil, e)
+        # N2's backward (round 5): the one fused kernel against the oracle's composition of channelnorm_kernel.cu:63-96 and
+        # resample2d_kernel.cu:75-198 on the forward's own output (C = 3 on tileable maps: the LDS-window kernel; else one lane per pixel)
+        gcat = rng.standard_normal((B, 3 * C + 3, H, W)).astype(np.float32)
+        want_pair = bool(rng.integers(0, 2))
+        gp, gf = fn2_capi.warp_diff_norm_cat_backward(D(pair), fld, D(got), D(gcat), 20.0, bil, want_pair)
+        diff = pair[:, :C] - got[:, 2 * C:3 * C]
+        gdiff = orc.chnorm_bwd(diff, np.ascontiguousarray(got[:, 3 * C + 2:]), np.ascontiguousarray(gcat[:, 3 * C + 2:]))
+        rgi, rgf = orc.resample_bwd(np.ascontiguousarray(pair[:, C:]), flow, np.ascontiguousarray(gcat[:, 2 * C:3 * C] - gdiff), 1, True)
+        rgf = rgf + gcat[:, 3 * C:3 * C + 2] * (np.float32(1.0) / np.float32(20.0))
+        s = max(1.0, float(np.abs(rgi).max()), float(np.abs(rgf).max()), float(np.abs(gdiff).max()))
+        e = mx(gf.cpu().numpy(), rgf) / s
+        if want_pair:
+            e = max(e, mx(gp[:, :C].cpu().numpy(), gcat[:, :C] + gdiff) / s, mx(gp[:, C:].cpu().numpy(), gcat[:, C:2 * C] + rgi) / s)
+        note("warp_diff_norm_cat_bwd", e); assert e <= (1e-4 if shifted else 2e-5), ("n2bwd", B, C, H, W, bil, want_pair, shifted, e)
         nimg += 1
 print("soak ok: %d correlation cases, %d image cases in %.0f s; worst normalised errors %s" % (ncorr, nimg, time.time() - t0, {k: float("%.3g" % v) for k, v in worst.items()}))
