@@ -295,7 +295,11 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
             const int c = chan(i);
             if (c >= CG) continue;                                    // uniform
             // inf / nan: an operand did not fit an f16 (class mask: sNaN, qNaN, -inf, +inf)
+#ifdef FN2_ABL_GPRESPLIT
+            if (false &&
+#else
             if ((VAR & 31) == 0 && lane_ok &&
+#endif
                 (__builtin_amdgcn_classf(vals[i][0], 0x207) | __builtin_amdgcn_classf(vals[i][1], 0x207) |
                  __builtin_amdgcn_classf(vals[i][2], 0x207) | __builtin_amdgcn_classf(vals[i][3], 0x207)))
                 bad |= 1u << i;
@@ -605,6 +609,15 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                         });
                         // two-term split in registers: slots (2q, 2q+1) -> one packed pair of each fragment
                         u4 vh, vl;
+#ifdef FN2_ABL_GPRESPLIT   // timing ablation (results wrong): what a gO image that arrives pre-scaled and pre-split as (h | l << 16) words
+                           // would cost here -- two v_perm_b32 per pair of slots instead of scale + split
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned a0 = __builtin_bit_cast(unsigned, w[(2 * q) & 3][q >> 1]), a1 = __builtin_bit_cast(unsigned, w[(2 * q + 1) & 3][q >> 1]);
+                            vh[q] = __builtin_amdgcn_perm(a1, a0, 0x05040100u);
+                            vl[q] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+                        }
+#else
 #pragma unroll
                         for (int q = 0; q < 4; ++q) w[q] = f16s::pk_scale(w[q], sc_g2);
 #pragma unroll
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(NWAVES * 64, 3) void corr_bwd_f16x2(Args p)
                             split2(w[(2 * q) & 3][q >> 1], w[(2 * q + 1) & 3][q >> 1], hq, lq);
                             vh[q] = hq; vl[q] = lq;
                         }
+#endif
                         gh[fi] = __builtin_bit_cast(h8, vh);
                         gl[fi] = __builtin_bit_cast(h8, vl);
                         __builtin_amdgcn_sched_barrier(0);   // one operand at a time: 8 loads in flight
