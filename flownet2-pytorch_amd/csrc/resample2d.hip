@@ -597,12 +597,13 @@ __global__ __launch_bounds__(TH * 16, (2 * TH * 16 + 255) / 256) void resample_f
 // Forward with ALL image channels of the window resident in LDS (C == NC, typically 3): a workgroup owns a TH x TW tile,
 // loads the NC windows at once (one barrier in the whole kernel instead of one per channel), forms the corner offsets and the
 // double-precision weights once per pixel and gathers the NC channels back to back.
-template <int TH, int TW, int R, int NC, int WPE = 4>
-__global__ __launch_bounds__(1024, WPE) void resample_fwd_tiled_all(const float *__restrict__ img, ImgStrides is,
+template <int TH, int TW, int R, int NC, int WPE = 4, int NTH = 1024>
+__global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *__restrict__ img, ImgStrides is,
                                                                 const float *__restrict__ flow, float *__restrict__ out,
                                                                 int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int bilinear)
 {
-    constexpr int NT = 1024, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
+    constexpr int NT = NTH, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
+    static_assert(TH * TW % NT == 0, "whole pixels per thread");
     __shared__ __attribute__((aligned(16))) float win[NC][WH * WW];
     const int tid = threadIdx.x;
     int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
