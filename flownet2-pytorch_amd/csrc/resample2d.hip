@@ -1064,8 +1064,6 @@ __device__ __forceinline__ void c3x_load_go(const C3xArgs &p, int b, long pix, l
     }
 }
 
-__device__ __forceinline__ unsigned t0_tile(unsigned bid, unsigned n) { return xcd_remap(bid, n); }
-
 template <int TH, int TW, int R, int NT, bool FUSED, bool SCATTER>
 __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
 {
@@ -1260,7 +1258,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         stamp(5);
         unsigned long long *d = p.dbg + (long)blockIdx.x * 8;
         for (int i = 0; i < 6; ++i) d[i] = ts[i];
-        d[6] = (unsigned long long)t0_tile(blockIdx.x, gridDim.x);
+        d[6] = (unsigned long long)xcd_remap(blockIdx.x, gridDim.x);   // the tile this workgroup took
     }
 }
 

@@ -74,6 +74,21 @@ def test_rejected_calls_return_codes_without_gpu():
     mis = ctypes.c_void_p(ctypes.addressof(buf) + 2)
     assert lib.fn2_channelnorm_forward(mis, p, 0, 1, 1, 2, 2, null) == -3          # FN2_EALIGN
     assert b"dtype" in lib.fn2_strerror(-2) and lib.fn2_strerror(0) == b"ok"
+    # ABI v2 entry points (round 5): fn2_warp_diff_norm_cat_backward, fn2_multiscale_loss
+    wb = lib.fn2_warp_diff_norm_cat_backward
+    assert wb(p, p, p, p, null, p, f32(20.0), 1, 0, 8, 8, 1, null) == -1           # C < 1
+    assert wb(p, p, p, p, null, p, f32(0.0), 1, 3, 8, 8, 1, null) == -1            # div_flow == 0
+    assert wb(p, p, p, p, null, p, f32(float("nan")), 1, 3, 8, 8, 1, null) == -1   # div_flow nan
+    assert wb(p, p, p, null, null, p, f32(20.0), 1, 3, 8, 8, 1, null) == -1        # no concat gradient
+    assert wb(p, p, p, p, null, null, f32(20.0), 1, 3, 8, 8, 1, null) == -1        # no flow gradient to write
+    assert wb(p, p, p, p, null, p, f32(20.0), 0, 3, 8, 8, 1, null) == 0            # empty batch
+    assert wb(mis, p, p, p, null, p, f32(20.0), 1, 3, 8, 8, 1, null) == -3         # FN2_EALIGN
+    outs = (ctypes.c_void_p * 1)(p.value)
+    w1 = (ctypes.c_float * 1)(0.32)
+    ml = lib.fn2_multiscale_loss
+    assert ml(outs, p, p, None, w1, f32(1.0), 3, 1, 8, 8, 4, 1, f32(0.05), p, ctypes.c_size_t(1 << 20), null) == -1    # norm must be 1 or 2
+    assert ml(outs, p, p, None, w1, f32(1.0), 2, 1, 8, 8, 3, 1, f32(0.05), p, ctypes.c_size_t(1 << 20), null) == -1    # start_scale not a power of two
+    assert ml(outs, p, p, None, w1, f32(1.0), 2, 1, 8, 8, 4, 1, f32(0.05), p, ctypes.c_size_t(0), null) == -1          # workspace too small
 
 
 def test_modules_keep_reference_names_and_signatures():
