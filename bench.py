@@ -197,8 +197,8 @@ def cpu_baseline(max_seconds=30.0):
     }
 
 
-# ---- the fastest reasonable CPU formulation of the same step (SURVEY.md 8d "no sandbagging"): whole-array PyTorch on all
-# host cores -- 441 shifted channel contractions with EXPLICIT backward passes for the correlation, grid_sample (border,
+# ---- a second CPU formulation of the same step (SURVEY.md 8d "no sandbagging"): whole-array PyTorch at torch's fastest thread
+# count on the host (16 of 256 cores; NOT faster than the OpenMP oracle on all cores: 12.9 against 13.7 pairs/s in round 5) -- 441 shifted channel contractions with EXPLICIT backward passes for the correlation, grid_sample (border,
 # align_corners: the closed form of resample2d_kernel.cu:15-72) and its autograd for the warp, the L2 norm
 # and its closed-form gradient.  Tolerance-level equal to the oracle (tests/test_bench_cpu_fast.py), not bit-exact: the
 # summation order is whatever the vectorised kernels choose.
@@ -313,9 +313,9 @@ def cpu_baseline_fast(max_seconds=15.0):
                 "sample": f"{len(times)} whole steps of the same workload (batch 8) after 1 warm-up step, median; fp32; vectorised PyTorch "
                           f"{torch.__version__} with torch.set_num_threads({nthreads}) (its fastest setting on this host, scripts/cpu_probe.py): "
                           "one batched GEMM per displacement row and image row + diagonal gather, explicit backward in the same shape "
-                          "(correlation); grid_sample border/align_corners + autograd (warp); closed-form norm gradient -- the fastest "
-                          "reasonable CPU formulation (the reference has no CPU path); `cpu_baseline` beside it is the bit-exact scalar "
-                          "restatement on all host cores",
+                          "(correlation); grid_sample border/align_corners + autograd (warp); closed-form norm gradient -- a vectorised "
+                          "formulation beside `cpu_baseline` (the bit-exact scalar restatement on all host cores, which is about as fast); "
+                          "the reference has no CPU path",
                 "seconds_per_step": round(med, 4)}
     finally:
         torch.set_num_threads(nthreads_before)
@@ -818,7 +818,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
-            # the fastest reasonable CPU formulation of the same step beside the bit-exact restatement
+            # a vectorised-PyTorch formulation of the same step beside the bit-exact restatement
             try:
                 line["cpu_baseline_fast"] = cpu_baseline_fast(args.cpu_fast_seconds)
                 line["gpu_over_cpu_fast"] = round(line["value"] / line["cpu_baseline_fast"]["value"], 1)
