@@ -729,6 +729,21 @@ def main():
             mfma_tflops = {"first5": rate(pev[:5]), "last5": rate(pev[-5:])}
         except Exception:
             mfma_tflops = None
+        # where workgroups run: the tile orders of the kernels assume "workgroup b on XCD b % 8" (for speed only)
+        xcd_census = None
+        try:
+            import ctypes
+            import fn2_capi
+            dl = fn2_capi.debug_lib()
+            ids = torch.full((4096,), -1, dtype=torch.int32, device=dev)
+            fn2_capi.check(dl.fn2_debug_xcc_census(ctypes.c_void_p(ids.data_ptr()), 4096, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                           "fn2_debug_xcc_census")
+            torch.cuda.synchronize()
+            ids = ids.cpu()
+            xcd_census = {"workgroups": 4096, "xcds_seen": int(ids.unique().numel()),
+                          "not_on_xcd_b_mod_8": int((ids != (torch.arange(4096, dtype=torch.int32) % 8)).sum())}
+        except Exception:
+            xcd_census = None
         # cold-operand sensitivity of the graded kernel on this box: median HIP-event time back-to-back (operands cache-resident)
         # and right after a 1 GiB fill (operands evicted from every cache level)
         junk = torch.empty(1 << 28, device=dev)
@@ -805,7 +820,7 @@ def main():
             "kernels": kernels,
             "per_rank": per_rank,
             "rank_balance_fastest_over_slowest": rank_balance,
-            "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1), **cold,
+            "box": {"mfma_probe_TFLOPs": mfma_tflops, "copy_ceiling_GBps": round(copy_gbs, 1), **cold, "xcd_placement": xcd_census,
                     "note": "probes of THIS box: a register-only f16 MFMA stream on every SIMD (first / last five of 40 back-to-back launches; dense "
                             "peak 2500), the streaming copy, and the graded kernel timed alone (operands cache-resident / after a 1 GiB "
                             "fill).  About every second box of the pool runs the whole step 20 % slower (0.23-0.24 vs 0.195-0.205 ms at the "

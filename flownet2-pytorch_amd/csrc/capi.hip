@@ -290,6 +290,21 @@ extern "C" int fn2_debug_mfma_probe(void *sink, int iters, int workgroups, doubl
     return fn2::launch_status();
 }
 
+// Where do the workgroups of a 1-D grid run?  out[b] = HW_REG_XCC_ID of workgroup b.  The kernels' tile orders (xcd_remap) assume
+// "workgroup b runs on XCD b % 8" for SPEED only (neighbouring tiles share an L2); bench.py reports the census with its box probes.
+__global__ void xcc_census_kernel(int *out)
+{
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 15;
+}
+extern "C" int fn2_debug_xcc_census(int *out, int workgroups, void *stream)
+{
+    if (!out || workgroups < 1) return FN2_EINVAL;
+    hipLaunchKernelGGL(xcc_census_kernel, dim3((unsigned)workgroups), dim3(64), 0, static_cast<hipStream_t>(stream), out);
+    return fn2::launch_status();
+}
+
 extern "C" int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, int nontemporal, void *stream)
 {
     if (!dst || !src || (bytes % 16) || !fn2::aligned(dst, 16) || !fn2::aligned(src, 16) || blocks < 1) return FN2_EINVAL;

@@ -34,6 +34,8 @@ int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, 
 /* register-only f16 MFMA stream on every SIMD (`workgroups` x 16 waves x iters x 8 MFMAs): a probe of the shader clock the box
  * sustains; *flop receives the FLOP count, `sink` is a device buffer of >= 4 KB that is never written */
 int fn2_debug_mfma_probe(void *sink, int iters, int workgroups, double *flop, void *stream);
+/* out[b] = HW_REG_XCC_ID of workgroup b of a 1-D grid of `workgroups` (device array of ints) */
+int fn2_debug_xcc_census(int *out, int workgroups, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,8 @@ EXPORTS = [
 # profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design; exported by
 # libflownet2_hip_debug.so only
 DEBUG_EXPORTS = ["fn2_debug_correlation_forward", "fn2_debug_correlation_backward", "fn2_debug_set_buffer",
-                 "fn2_debug_resample2d_forward", "fn2_debug_resample2d_backward", "fn2_debug_stream_copy", "fn2_debug_mfma_probe"]
+                 "fn2_debug_resample2d_forward", "fn2_debug_resample2d_backward", "fn2_debug_stream_copy", "fn2_debug_mfma_probe",
+                 "fn2_debug_xcc_census"]
 
 _lib = None
 _dbg = None
