@@ -63,3 +63,19 @@ def graded_corr_inputs(fixture):
     if not np.array_equal(chk, fixture["input_checksum"]):
         pytest.skip("numpy's default_rng draws differ from the ones the fixture was generated with")
     return in1, in2, gout
+
+
+def full_size_inputs(fixture):
+    """Inputs of tests/golden/fullsize_*.npz, regenerated from the fixture's seed as tests/golden/make_golden_full_size.py drew them."""
+    B, C, H, W = (int(v) for v in fixture["shape"])
+    rng = np.random.default_rng(int(fixture["seed"]))
+    img = rng.uniform(-0.5, 0.5, (B, C, H, W)).astype(np.float32)
+    flow = (rng.standard_normal((B, 2, H, W)) * 4.0).astype(np.float32)
+    flow.reshape(-1)[rng.integers(0, flow.size, flow.size // 100)] *= np.float32(20.0)
+    gout = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    gnorm = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+    img[0, :, 5, 7] = 0.0
+    chk = np.array([float(np.sum(a.astype(np.float64) * np.arange(1, a.size + 1, dtype=np.float64).reshape(a.shape) % 7.0)) for a in (img, flow, gout, gnorm)])
+    if not np.array_equal(chk, fixture["input_checksum"]):
+        pytest.skip("numpy's default_rng draws differ from the ones the fixture was generated with")
+    return img, flow, gout, gnorm

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_files, graded_corr_inputs, max_abs
+from conftest import full_size_inputs, golden_files, graded_corr_inputs, max_abs
 
 
 @pytest.mark.parametrize("path", golden_files("corr"), ids=os.path.basename)
@@ -55,6 +55,27 @@ def test_corr_graded_geometry_golden(oracle, path):
     assert max_abs(g1[:, g["channels"]], g["g1_channels"]) == 0.0 and max_abs(g2[:, g["channels"]], g["g2_channels"]) == 0.0
     assert np.array_equal(g1.astype(np.float64).sum(axis=(0, 2, 3)), g["g1_sum"])
     assert np.array_equal(g2.astype(np.float64).sum(axis=(0, 2, 3)), g["g2_sum"])
+
+
+@pytest.mark.parametrize("path", golden_files("fullsize"), ids=os.path.basename)
+def test_full_size_resample_chnorm_golden(oracle, path):
+    """Resample2d and ChannelNorm at the BASELINE shape (8 x 3 x 384 x 512, the SURVEY's flow): the restated oracle reproduces the
+    reference's device code bit for bit on the kept rows and on the float64 sums of every plane."""
+    g = np.load(path)
+    img, flow, gout, gnorm = full_size_inputs(g)
+    rows = g["rows"]
+
+    def same(name, a):
+        assert max_abs(a[:, :, rows], g[name + "_rows"]) == 0.0, name
+        assert np.array_equal(a.astype(np.float64).sum(axis=(2, 3)), g[name + "_sum"]), name
+    same("warp", oracle.resample_fwd(img, flow, 1, True))
+    same("warp_nearest", oracle.resample_fwd(img, flow, 1, False))
+    gi, gf = oracle.resample_bwd(img, flow, gout, 1, True)
+    same("gimg", gi)
+    same("gflow", gf)
+    n = oracle.chnorm_fwd(img)
+    same("norm", n)
+    same("gnorm_in", oracle.chnorm_bwd(img, n, gnorm))
 
 
 def test_golden_present():

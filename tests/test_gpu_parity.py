@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_files, graded_corr_inputs, max_abs
+from conftest import full_size_inputs, golden_files, graded_corr_inputs, max_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -146,6 +146,40 @@ def test_resample2d_golden(dev, path):
     assert resample2d_cuda.backward(img, flow, gout, gimg, gflow, 1, True) == 1
     assert max_abs(gflow.cpu().numpy(), g["gflow"]) <= 1e-6
     assert max_abs(gimg.cpu().numpy(), g["gimg"]) <= 5e-6 * max(1.0, float(np.abs(g["gimg"]).max()))
+
+
+@pytest.mark.parametrize("path", golden_files("fullsize"), ids=os.path.basename)
+def test_full_size_resample_chnorm_golden(dev, path):
+    """Resample2d and ChannelNorm at the BASELINE shape (8 x 3 x 384 x 512, the SURVEY's white-noise flow with 1 % outliers) against
+    the REFERENCE's own device code (tests/golden/make_golden_full_size.py): the kept rows of every tensor and the float64 sums of every
+    (batch, channel) plane -- forward (bilinear and nearest), both gradients of the warp, the norm and its gradient."""
+    import channelnorm_cuda
+    import resample2d_cuda
+    g = np.load(path)
+    img, flow, gout, gnorm = (to_dev(a, dev) for a in full_size_inputs(g))
+    rows = g["rows"]
+
+    def close(name, t, tol, sum_tol):
+        a = t.cpu().numpy()
+        scale = max(1.0, float(np.abs(g[name + "_rows"]).max()))
+        assert max_abs(a[:, :, rows], g[name + "_rows"]) <= tol * scale, name
+        err = np.abs(a.astype(np.float64).sum(axis=(2, 3)) - g[name + "_sum"])
+        assert np.all(err <= sum_tol * np.maximum(g[name + "_abs"], 1.0)), (name, float(err.max()))
+    for bil, name in ((True, "warp"), (False, "warp_nearest")):
+        out = torch.full_like(img, float("nan"))
+        assert resample2d_cuda.forward(img, flow, out, 1, bil) == 1
+        close(name, out, 1e-6, 1e-6)
+    gi, gf = torch.zeros_like(img), torch.full_like(flow, float("nan"))
+    assert resample2d_cuda.backward(img, flow, gout, gi, gf, 1, True) == 1
+    close("gflow", gf, 1e-6, 1e-6)
+    close("gimg", gi, 5e-6, 1e-6)            # fp32 atomics: an order of their own
+    n = torch.full((img.shape[0], 1, img.shape[2], img.shape[3]), float("nan"), device=dev)
+    assert channelnorm_cuda.forward(img, n, 2) == 1
+    close("norm", n, 1e-6, 1e-6)
+    gin = torch.full_like(img, float("nan"))
+    assert channelnorm_cuda.backward(img, n, gnorm, gin, 2) == 1
+    close("gnorm_in", gin, 1e-5, 1e-6)
+    assert float(gin[0, :, 5, 7].abs().max()) == 0.0     # the exactly-zero pixel: 0, not nan (channelnorm_kernel.cu:93)
 
 
 @pytest.mark.parametrize("shape", [(1, 16, 32), (2, 100, 200), (1, 33, 68), (3, 64, 64), (2, 97, 260), (1, 48, 96)])
