@@ -127,6 +127,48 @@ int warp_diff_norm_cat_backward_hip(at::Tensor &pair, at::Tensor &flow, at::Tens
     return 1;
 }
 
+// models.py:157-161 / :170-174: ||pair[:, :C] - warp(pair[:, C:], flow)||_2 (fn2_warp_diff_norm) and its flow gradient
+at::Tensor warp_diff_norm_hip(at::Tensor &pair, at::Tensor &flow, bool bilinear)
+{
+    const char *op = "resample2d_cuda.warp_diff_norm";
+    check_gpu(pair, op, "pair");
+    check_same(pair, flow, op, "flow");
+    TORCH_CHECK(pair.scalar_type() == at::kFloat, op, ": float32 tensors expected, got ", pair.scalar_type());
+    TORCH_CHECK(pair.dim() == 4 && flow.dim() == 4 && pair.size(1) % 2 == 0 && pair.size(1) > 0, op, ": pair must be 4-D with two images");
+    const int B = pair.size(0), C = pair.size(1) / 2, H = pair.size(2), W = pair.size(3);
+    TORCH_CHECK(flow.size(0) == B && flow.size(1) == 2 && flow.size(2) == H && flow.size(3) == W, op, ": flow ", flow.sizes(),
+                " does not match pair ", pair.sizes());
+    c10::DeviceGuard guard(pair.device());
+    at::Tensor p = pair.contiguous(), f = flow.contiguous();
+    at::Tensor out = at::empty({B, 1, H, W}, pair.options());
+    check_rc(fn2_warp_diff_norm(p.data_ptr<float>(), f.data_ptr<float>(), out.data_ptr<float>(), B, C, H, W, bilinear ? 1 : 0,
+                                current_stream(pair)), op);
+    return out;
+}
+
+at::Tensor warp_diff_norm_backward_hip(at::Tensor &pair, at::Tensor &flow, at::Tensor &norm, at::Tensor &gradNorm, bool bilinear)
+{
+    const char *op = "resample2d_cuda.warp_diff_norm_backward";
+    check_gpu(pair, op, "pair");
+    check_same(pair, flow, op, "flow");
+    check_same(pair, norm, op, "norm");
+    check_same(pair, gradNorm, op, "gradNorm");
+    TORCH_CHECK(pair.scalar_type() == at::kFloat, op, ": float32 tensors expected, got ", pair.scalar_type());
+    TORCH_CHECK(pair.dim() == 4 && flow.dim() == 4 && pair.size(1) % 2 == 0 && pair.size(1) > 0, op, ": pair must be 4-D with two images");
+    const int B = pair.size(0), C = pair.size(1) / 2, H = pair.size(2), W = pair.size(3);
+    TORCH_CHECK(flow.size(0) == B && flow.size(1) == 2 && flow.size(2) == H && flow.size(3) == W, op, ": flow ", flow.sizes(),
+                " does not match pair ", pair.sizes());
+    TORCH_CHECK(norm.sizes() == gradNorm.sizes() && norm.dim() == 4 && norm.size(0) == B && norm.size(1) == 1 && norm.size(2) == H &&
+                    norm.size(3) == W, op, ": norm / gradNorm must be [", B, ", 1, ", H, ", ", W, "]");
+    TORCH_CHECK(pair.is_contiguous() && flow.is_contiguous() && norm.is_contiguous(), op, ": pair, flow and norm must be contiguous");
+    c10::DeviceGuard guard(pair.device());
+    at::Tensor gn = gradNorm.contiguous();
+    at::Tensor gflow = at::empty(flow.sizes(), flow.options());
+    check_rc(fn2_warp_diff_norm_backward(pair.data_ptr<float>(), flow.data_ptr<float>(), norm.data_ptr<float>(), gn.data_ptr<float>(),
+                                         gflow.data_ptr<float>(), B, C, H, W, bilinear ? 1 : 0, current_stream(pair)), op);
+    return gflow;
+}
+
 // forward / backward with their outputs allocated here (the wrappers of this repository; the reference's signatures stay above)
 at::Tensor resample2d_forward_alloc(at::Tensor &input1, at::Tensor &input2, int kernel_size, bool bilinear)
 {
@@ -162,4 +204,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("warp_diff_norm_cat", &warp_diff_norm_cat_hip,
           "cat(pair, warp(second image, flow), flow / div_flow, ||first image - warped||) in one pass");
     m.def("warp_diff_norm_cat_backward", &warp_diff_norm_cat_backward_hip, "backward of warp_diff_norm_cat in one pass");
+    m.def("warp_diff_norm", &warp_diff_norm_hip, "||first image - warp(second image, flow)|| in one pass (models.py:157-161)");
+    m.def("warp_diff_norm_backward", &warp_diff_norm_backward_hip, "flow gradient of warp_diff_norm in one pass");
 }

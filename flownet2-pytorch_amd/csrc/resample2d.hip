@@ -342,7 +342,7 @@ __device__ __forceinline__ void lds_add_f64(float *, float) {}   // never called
 // kernel writes cat((pair, warped, flow / div_flow, ||pair[:, :C] - warped||_2), 1) = B x (3C+3) x H x W in one pass:
 // the warped channel, the copy of both images (the second one comes from the LDS window), the squared difference
 // accumulated in channel order as channelnorm_kernel.cu:41-52 does, then the flow and the norm planes.
-template <int TH, int TW, int R, bool FUSE = false>
+template <int TH, int TW, int R, int FUSE = 0>   // 0: Resample2d; 1: row N2's concat; 2: the norm plane only (models.py:157-161)
 __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__restrict__ img, ImgStrides is,
                                                             const float *__restrict__ flow, float *__restrict__ out,
                                                             int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y,
@@ -456,12 +456,14 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
             if (!FUSE) store_out(out + ((long)b * C + c) * HW + (y * W + x), val);
             else {
                 const int pix = y * W + x;
-                float *ob = out + (long)b * (3 * C + 3) * HW + pix;
                 const float v0 = pair[((long)b * 2 * C + c) * HW + pix];
-                const float v1 = wc[(y - wy0) * WW + (x - wx0)];        // the pixel itself is always inside the window
-                store_out(ob + (long)c * HW, v0);
-                store_out(ob + (long)(C + c) * HW, v1);
-                store_out(ob + (long)(2 * C + c) * HW, val);
+                if (FUSE == 1) {
+                    float *ob = out + (long)b * (3 * C + 3) * HW + pix;
+                    const float v1 = wc[(y - wy0) * WW + (x - wx0)];        // the pixel itself is always inside the window
+                    store_out(ob + (long)c * HW, v0);
+                    store_out(ob + (long)(C + c) * HW, v1);
+                    store_out(ob + (long)(2 * C + c) * HW, val);
+                }
                 const float d = v0 - val;                               // models.py:134
                 ssq[k] = ssq[k] + d * d;                                // channelnorm_kernel.cu:47-50
             }
@@ -476,6 +478,10 @@ __global__ __launch_bounds__(1024, 8) void resample_fwd_tiled(const float *__res
             const int x = X0 + idx % TW, y = Y0 + idx / TW;
             if (!(flags[k] & LIVE)) continue;
             const int pix = y * W + x;
+            if (FUSE == 2) {                                            // only ||first image - warped||: B x 1 x H x W
+                store_out(out + (long)b * HW + pix, __fsqrt_rn(ssq[k]));
+                continue;
+            }
             float *ob = out + (long)b * (3 * C + 3) * HW + pix;
             // models.py:138 `flow / self.div_flow` on a GPU tensor: PyTorch multiplies by the fp32 reciprocal of a scalar divisor
             const float inv_div = 1.0f / div_flow;
@@ -1042,16 +1048,20 @@ struct C3xArgs {
     float *gimg; long gimg_bs;                // scatter target, 3 planes of Hi x Wi per item, gimg_bs floats between items
     float *gflow;
     int B, Hi, Wi, H, W, tiles_x, tiles_y, abl;
+    int bilinear;                             // FUSED == 2: how the forward sampled (its value is recomputed)
     float inv_div_flow;
     unsigned long long *dbg;                  // profiling (abl & 8): the debug library's stamp buffer (fn2_debug_set_buffer), else null
 };
 
-template <bool FUSED>
+template <int FUSED>
 __device__ __forceinline__ void c3x_load_go(const C3xArgs &p, int b, long pix, long HW, float go[3], bool write_gpair0)
 {
-    if constexpr (!FUSED) {
+    if constexpr (FUSED == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) go[c] = p.gout[((long)b * 3 + c) * HW + pix];
+    } else if constexpr (FUSED == 2) {   // the first image's pixel: the gradient is formed at the gather, from the recomputed warp
+#pragma unroll
+        for (int c = 0; c < 3; ++c) go[c] = p.pair[((long)b * 6 + c) * HW + pix];
     } else {
         const float gn = p.gcat[((long)b * 12 + 11) * HW + pix], nrm = p.outcat[((long)b * 12 + 11) * HW + pix];
 #pragma unroll
@@ -1064,9 +1074,13 @@ __device__ __forceinline__ void c3x_load_go(const C3xArgs &p, int b, long pix, l
     }
 }
 
-template <int TH, int TW, int R, int NT, bool FUSED, bool SCATTER>
+// FUSED: 0 = Resample2d's backward; 1 = row N2's concat (above); 2 = the norm-only form (models.py:157-161, :170-174:
+// ||first image - warped||_2 with no concat): gcat / outcat are the B x 1 x H x W gradient of the norm and the norm, the warped image
+// was never stored and is recomputed at the gather from the same corners with the forward's arithmetic; gather only (SCATTER false).
+template <int TH, int TW, int R, int NT, int FUSED, bool SCATTER>
 __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
 {
+    static_assert(FUSED != 2 || !SCATTER, "the norm-only form is gather-only");
     constexpr int WH = TH + 2 * R, WW = TW + 2 * R, WWP = WW + 1, PPT = TH * TW / NT, CELLS = WH * WWP, C = 3;
     constexpr int NW = (WH * (WW / 4) + NT - 1) / NT;
     constexpr int WIN_BYTES = SCATTER ? CELLS * 12 : 3 * WH * WW * 4;
@@ -1097,6 +1111,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
     stamp(0);
 
     float fdx[PPT], fdy[PPT], go[PPT][C];
+    float gnv[FUSED == 2 ? PPT : 1], nrv[FUSED == 2 ? PPT : 1], alv[FUSED == 2 ? PPT : 1], btv[FUSED == 2 ? PPT : 1];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
@@ -1105,6 +1120,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         const long pix = live ? (long)y * W + x : 0;
         fdx[k] = p.flow[(long)b * 2 * HW + pix]; fdy[k] = p.flow[(long)b * 2 * HW + HW + pix];
         c3x_load_go<FUSED>(p, b, pix, HW, go[k], live);
+        if (FUSED == 2) { gnv[k] = p.gcat[(long)b * HW + pix]; nrv[k] = p.outcat[(long)b * HW + pix]; }
     }
     if (SCATTER)
         for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
@@ -1130,6 +1146,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         const int ixL = f2i_sat(fx), ixR = f2i_sat(fx + 1.0f), iyT = f2i_sat(fy), iyB = f2i_sat(fy + 1.0f);
         gam_y[k] = 1 - (xf - fx);   // c == 1 branch (:169)
         gam_x[k] = 1 - (yf - fy);   // c == 0 branch (:182)
+        if (FUSED == 2) { alv[k] = xf - fx; btv[k] = yf - fy; }   // the forward's alpha, beta (resample2d_kernel.cu:45-46)
         {   // gather corners: clamped with the FLOW dims (:163-166), then to the image
             const int xL = clampi(clampi(ixL, 0, W - 1), 0, Wi - 1), xR = clampi(clampi(ixR, 0, W - 1), 0, Wi - 1);
             const int yT = clampi(clampi(iyT, 0, H - 1), 0, Hi - 1), yB = clampi(clampi(iyB, 0, H - 1), 0, Hi - 1);
@@ -1222,7 +1239,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         float out_dx = 0.0f, out_dy = 0.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float g = go[k][c];
+            float g = go[k][c];
             float iTL, iTR, iBL, iBR;
             if (p.abl & 4) { iTL = iTR = iBL = iBR = g; }
             else if (fl & G_IN) {
@@ -1233,6 +1250,22 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
                 const float *I = img + (long)b * is.b + (long)c * is.c;
                 const int ox = (fl & G_DX) ? (int)is.w : 0, oy = (fl & G_DY) ? (int)is.h : 0;
                 iTL = I[gb]; iTR = I[gb + ox]; iBL = I[gb + oy]; iBR = I[gb + oy + ox];
+            }
+            if constexpr (FUSED == 2) {
+                // the forward's sample (resample2d_kernel.cu:56-59 / :66-69) from the same four corners, then ChannelNorm's gradient of
+                // the difference (channelnorm_kernel.cu:93) with the sign of d(diff)/d(warped)
+                float val;
+                if (p.bilinear) {
+                    const double a = (double)alv[k], be = (double)btv[k];
+                    val = 0.0f;
+                    val = val + (float)(((1. - a) * (1. - be)) * (double)iTL);
+                    val = val + (float)((a * (1. - be)) * (double)iTR);
+                    val = val + (float)(((1. - a) * be) * (double)iBL);
+                    val = val + (float)((a * be) * (double)iBR);
+                } else {
+                    val = alv[k] >= 0.5f ? (btv[k] >= 0.5f ? iBR : iTR) : (btv[k] >= 0.5f ? iBL : iTL);
+                }
+                g = 0.0f - chnorm_grad(gnv[k], g - val, nrv[k]);
             }
             out_dy = out_dy + (gam_y[k] * g) * iBL;       // (:172-177)
             out_dy = out_dy - (gam_y[k] * g) * iTL;
@@ -1246,7 +1279,7 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
         const long pix = (long)y * W + x;
-        if (FUSED) {   // + the gradient through flow / div_flow = flow * (1 / div_flow) (models.py:137)
+        if (FUSED == 1) {   // + the gradient through flow / div_flow = flow * (1 / div_flow) (models.py:137)
             out_dx = out_dx + p.gcat[((long)b * 12 + 9) * HW + pix] * p.inv_div_flow;
             out_dy = out_dy + p.gcat[((long)b * 12 + 10) * HW + pix] * p.inv_div_flow;
         }
@@ -1267,8 +1300,10 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
 __global__ __launch_bounds__(256) void warp_diff_norm_cat_bwd_kernel(const float *__restrict__ pair, const float *__restrict__ flow,
                                                                      const float *__restrict__ outcat, const float *__restrict__ gcat,
                                                                      float *__restrict__ gpair, float *__restrict__ gflow,
-                                                                     int C, int H, int W, long npix, float inv_div_flow)
+                                                                     int C, int H, int W, long npix, float inv_div_flow, int norm_only, int bilinear)
 {
+    // norm_only (models.py:157-161 differentiated): outcat / gcat are the B x 1 x H x W norm and its gradient; the warped image is not
+    // stored and is recomputed with the forward's arithmetic; no concat terms
     const long HW = (long)H * W;
     const int CC = 3 * C + 3;
     for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
@@ -1283,13 +1318,27 @@ __global__ __launch_bounds__(256) void warp_diff_norm_cat_bwd_kernel(const float
         const float gam_y = 1 - (xf - fx), gam_x = 1 - (yf - fy);
         const float alpha = xf - (float)f2i_sat(xf), beta = yf - (float)f2i_sat(yf);
         const float s00 = (1 - alpha) * (1 - beta), s01 = alpha * (1 - beta), s10 = (1 - alpha) * beta, s11 = alpha * beta;
-        const float gn = gcat[((long)b * CC + 3 * C + 2) * HW + pix], nrm = outcat[((long)b * CC + 3 * C + 2) * HW + pix];
+        const float gn = norm_only ? gcat[(long)b * HW + pix] : gcat[((long)b * CC + 3 * C + 2) * HW + pix];
+        const float nrm = norm_only ? outcat[(long)b * HW + pix] : outcat[((long)b * CC + 3 * C + 2) * HW + pix];
         float out_dx = 0.0f, out_dy = 0.0f;
         for (int c = 0; c < C; ++c) {
-            const float diff = pair[((long)b * 2 * C + c) * HW + pix] - outcat[((long)b * CC + 2 * C + c) * HW + pix];
-            const float gd = chnorm_grad(gn, diff, nrm);
-            const float go = gcat[((long)b * CC + 2 * C + c) * HW + pix] - gd;
             const float *I = pair + ((long)b * 2 * C + C + c) * HW;
+            float warped;
+            if (!norm_only) warped = outcat[((long)b * CC + 2 * C + c) * HW + pix];
+            else if (bilinear) {
+                const double a = (double)(xf - fx), be = (double)(yf - fy);
+                warped = 0.0f;
+                warped = warped + (float)(((1. - a) * (1. - be)) * (double)I[yT * W + xL]);
+                warped = warped + (float)((a * (1. - be)) * (double)I[yT * W + xR]);
+                warped = warped + (float)(((1. - a) * be) * (double)I[yB * W + xL]);
+                warped = warped + (float)((a * be) * (double)I[yB * W + xR]);
+            } else {
+                const int xN = clampi(d2i_sat(floor((double)xf + 0.5)), 0, W - 1), yN = clampi(d2i_sat(floor((double)yf + 0.5)), 0, H - 1);
+                warped = I[yN * W + xN];
+            }
+            const float diff = pair[((long)b * 2 * C + c) * HW + pix] - warped;
+            const float gd = chnorm_grad(gn, diff, nrm);
+            const float go = norm_only ? 0.0f - gd : gcat[((long)b * CC + 2 * C + c) * HW + pix] - gd;
             if (gpair) {
                 gpair[((long)b * 2 * C + c) * HW + pix] = gcat[((long)b * CC + c) * HW + pix] + gd;
                 float *G = gpair + ((long)b * 2 * C + C + c) * HW;
@@ -1308,6 +1357,7 @@ __global__ __launch_bounds__(256) void warp_diff_norm_cat_bwd_kernel(const float
             out_dx = out_dx + ((1 - gam_x) * go) * iBR;
             out_dx = out_dx - ((1 - gam_x) * go) * iBL;
         }
+        if (norm_only) { gflow[(long)b * 2 * HW + pix] = out_dx; gflow[(long)b * 2 * HW + HW + pix] = out_dy; continue; }
         gflow[(long)b * 2 * HW + pix] = out_dx + gcat[((long)b * CC + 3 * C) * HW + pix] * inv_div_flow;
         gflow[(long)b * 2 * HW + HW + pix] = out_dy + gcat[((long)b * CC + 3 * C + 1) * HW + pix] * inv_div_flow;
     }
@@ -1316,7 +1366,7 @@ __global__ __launch_bounds__(256) void warp_diff_norm_cat_bwd_kernel(const float
 // N2 for shapes the tiled kernel does not take: one lane per pixel, corners gathered from global memory.
 __global__ __launch_bounds__(256) void warp_diff_norm_cat_kernel(const float *__restrict__ pair, const float *__restrict__ flow,
                                                                  float *__restrict__ out, int C, int H, int W, long npix,
-                                                                 int bilinear, float div_flow)
+                                                                 int bilinear, float div_flow, int norm_only)
 {
     const long HW = (long)H * W;
     for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < npix; g += (long)gridDim.x * blockDim.x) {
@@ -1350,12 +1400,15 @@ __global__ __launch_bounds__(256) void warp_diff_norm_cat_kernel(const float *__
                 val = val + (float)((a * be) * (double)I[(long)yB * W + xR]);
             } else val = I[(long)yT * W + xL];
             const float v0 = pair[((long)b * 2 * C + c) * HW + pix];
-            ob[(long)c * HW] = v0;
-            ob[(long)(C + c) * HW] = I[pix];
-            ob[(long)(2 * C + c) * HW] = val;
+            if (!norm_only) {
+                ob[(long)c * HW] = v0;
+                ob[(long)(C + c) * HW] = I[pix];
+                ob[(long)(2 * C + c) * HW] = val;
+            }
             const float d = v0 - val;
             ssq = ssq + d * d;
         }
+        if (norm_only) { out[(long)b * HW + pix] = __fsqrt_rn(ssq); continue; }
         const float inv_div = 1.0f / div_flow;   // as PyTorch divides a GPU tensor by a scalar
         ob[(long)(3 * C) * HW] = dx * inv_div;
         ob[(long)(3 * C + 1) * HW] = dy * inv_div;
@@ -1392,7 +1445,7 @@ static fn2::C3xArgs c3x_args(const float *img, fn2::ImgStrides is, const float *
     a.img = img; a.is = is; a.flow = flow; a.gout = nullptr; a.gcat = a.pair = a.outcat = nullptr; a.gpair0 = nullptr;
     a.gimg = gimg; a.gimg_bs = gimg_bs; a.gflow = gflow;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = (H + 31) / 32; a.abl = abl;
-    a.inv_div_flow = 0.0f;
+    a.inv_div_flow = 0.0f; a.bilinear = 1;
 #ifdef FN2_DEBUG_BUILD
     a.dbg = static_cast<unsigned long long *>(fn2::corr_f16x2_get_debug_buffer());
 #else
@@ -1554,7 +1607,7 @@ static int resample2d_backward_impl(const float *img, const int64_t *img_strides
             if (C == 3) {
                 C3xArgs a = c3x_args(img, is, flow, grad_img, (long)C * Hi * Wi, grad_flow, B, Hi, Wi, H, W, tiles_x, abl);
                 a.gout = grad_out;
-                hipLaunchKernelGGL((resample_bwd_c3x<32, TW, 16, 1024, false, true>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+                hipLaunchKernelGGL((resample_bwd_c3x<32, TW, 16, 1024, 0, true>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
             } else FN2_RB(32, 16, 8, 1);
             break;
         }
@@ -1607,7 +1660,7 @@ extern "C" int fn2_warp_diff_norm_cat(const float *pair, const float *flow, floa
 #define FN2_WF(TH)                                                                                                      \
     do {                                                                                                                \
         const int tiles_y = (H + TH - 1) / TH;                                                                          \
-        hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16, true>), dim3((unsigned)((long)B * tiles_x * tiles_y)),       \
+        hipLaunchKernelGGL((resample_fwd_tiled<TH, TW, 16, 1>), dim3((unsigned)((long)B * tiles_x * tiles_y)),          \
                            dim3(1024), 0, s, img1, is, flow, out, C, H, W, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0, \
                            pair, div_flow);                                                                             \
     } while (0)
@@ -1615,7 +1668,7 @@ extern "C" int fn2_warp_diff_norm_cat(const float *pair, const float *flow, floa
 #undef FN2_WF
     } else {
         hipLaunchKernelGGL(warp_diff_norm_cat_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, out, C, H, W,
-                           npix, (bilinear & 1) ? 1 : 0, div_flow);
+                           npix, (bilinear & 1) ? 1 : 0, div_flow, 0);
     }
     return launch_status();
 }
@@ -1653,11 +1706,70 @@ extern "C" int fn2_warp_diff_norm_cat_backward(const float *pair, const float *f
     if (c3x_ok(is, img1, C, H, W, H, W)) {
         C3xArgs a = c3x_args(img1, is, flow, grad_pair ? grad_pair + 3 * HW : nullptr, 6 * HW, grad_flow, B, H, W, H, W, (W + 63) / 64, 0);
         a.gcat = grad_cat; a.pair = pair; a.outcat = out_cat; a.gpair0 = grad_pair; a.inv_div_flow = inv;
-        if (grad_pair) hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, true, true>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, true, false>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+        if (grad_pair) hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, 1, true>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, 1, false>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
         return launch_status();
     }
     hipLaunchKernelGGL(warp_diff_norm_cat_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, out_cat, grad_cat, grad_pair,
-                       grad_flow, C, H, W, npix, inv);
+                       grad_flow, C, H, W, npix, inv, 0, 1);
+    return launch_status();
+}
+
+// models.py:157-161 / :170-174: ||pair[:, :C] - Resample2d(pair[:, C:], flow)||_2 with no concat -- row N2's forward kernel storing
+// only the norm plane
+extern "C" int fn2_warp_diff_norm(const float *pair, const float *flow, float *out_norm, int B, int C, int H, int W, int bilinear, void *stream)
+{
+    using namespace fn2;
+    bilinear = bilinear != 0 ? 1 : 0;
+    if (B < 0 || C < 1 || H < 1 || W < 1) return FN2_EINVAL;
+    if ((long)B * H * W == 0) return FN2_OK;
+    if (!pair || !flow || !out_norm) return FN2_EINVAL;
+    if (!aligned(pair, 4) || !aligned(flow, 4) || !aligned(out_norm, 4)) return FN2_EALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    if ((W % 4 == 0) && aligned(pair, 16) && (H >= 16) && (W >= 32)) {
+        ImgStrides is;
+        is.b = 2 * C * HW; is.c = HW; is.h = W; is.w = 1;
+        const float *img1 = pair + (long)C * HW;
+        const int tiles_x = (W + 63) / 64;
+#define FN2_WN(TH)                                                                                                      \
+    do {                                                                                                                \
+        const int tiles_y = (H + TH - 1) / TH;                                                                          \
+        hipLaunchKernelGGL((resample_fwd_tiled<TH, 64, 16, 2>), dim3((unsigned)((long)B * tiles_x * tiles_y)),          \
+                           dim3(1024), 0, s, img1, is, flow, out_norm, C, H, W, H, W, tiles_x, tiles_y, bilinear, pair, 1.0f); \
+    } while (0)
+        if (tile_height(B, H, tiles_x) == 48) FN2_WN(48); else FN2_WN(32);
+#undef FN2_WN
+    } else {
+        hipLaunchKernelGGL(warp_diff_norm_cat_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, out_norm, C, H, W, npix,
+                           bilinear, 1.0f, 1);
+    }
+    return launch_status();
+}
+
+// ... and its backward with respect to the flow (the pair is the network's input in FlowNet2; compose the unfused entry points when it
+// needs a gradient): grad_flow = Resample2d's flow gradient for g_warped = -grad_norm * diff / (norm + 1e-9), the warp recomputed
+extern "C" int fn2_warp_diff_norm_backward(const float *pair, const float *flow, const float *norm, const float *grad_norm,
+                                           float *grad_flow, int B, int C, int H, int W, int bilinear, void *stream)
+{
+    using namespace fn2;
+    bilinear = bilinear != 0 ? 1 : 0;
+    if (B < 0 || C < 1 || H < 1 || W < 1) return FN2_EINVAL;
+    if ((long)B * H * W == 0) return FN2_OK;
+    if (!pair || !flow || !norm || !grad_norm || !grad_flow) return FN2_EINVAL;
+    if (!aligned(pair, 4) || !aligned(flow, 4) || !aligned(norm, 4) || !aligned(grad_norm, 4) || !aligned(grad_flow, 4)) return FN2_EALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    ImgStrides is;
+    is.b = 2L * C * HW; is.c = HW; is.h = W; is.w = 1;
+    const float *img1 = pair + (long)C * HW;
+    if (c3x_ok(is, img1, C, H, W, H, W)) {
+        C3xArgs a = c3x_args(img1, is, flow, nullptr, 0, grad_flow, B, H, W, H, W, (W + 63) / 64, 0);
+        a.gcat = grad_norm; a.pair = pair; a.outcat = norm; a.bilinear = bilinear;
+        hipLaunchKernelGGL((resample_bwd_c3x<32, 64, 16, 1024, 2, false>), dim3(c3x_grid(a)), dim3(1024), 0, s, a);
+        return launch_status();
+    }
+    hipLaunchKernelGGL(warp_diff_norm_cat_bwd_kernel, dim3(stream_grid(npix)), dim3(256), 0, s, pair, flow, norm, grad_norm,
+                       static_cast<float *>(nullptr), grad_flow, C, H, W, npix, 0.0f, 1, bilinear);
     return launch_status();
 }

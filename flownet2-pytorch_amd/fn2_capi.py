@@ -19,7 +19,7 @@ EXPORTS = [
     "fn2_correlation_backward", "fn2_correlation_backward_ex",
     "fn2_correlation_backward_fused_workspace_bytes", "fn2_correlation_backward_fused",
     "fn2_resample2d_forward", "fn2_resample2d_backward", "fn2_warp_diff_norm_cat",
-    "fn2_warp_diff_norm_cat_backward",
+    "fn2_warp_diff_norm_cat_backward", "fn2_warp_diff_norm", "fn2_warp_diff_norm_backward",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
     "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe", "fn2_multiscale_loss",
 ]
@@ -183,6 +183,28 @@ def warp_diff_norm_cat_backward(pair, flow, out_cat, grad_cat, div_flow=20.0, bi
                                                     _p(gflow), ctypes.c_float(div_flow), B, C, H, W, 1 if bilinear else 0,
                                                     _stream(pair)), "fn2_warp_diff_norm_cat_backward")
     return gpair, gflow
+
+
+def warp_diff_norm(pair, flow, bilinear=True):
+    """||pair[:, :C] - warp(pair[:, C:], flow)||_2 (models.py:157-161): B x 1 x H x W."""
+    import torch
+    B, C2, H, W = pair.shape
+    assert pair.is_contiguous() and flow.is_contiguous() and pair.dtype == torch.float32
+    out = torch.full((B, 1, H, W), float("nan"), dtype=pair.dtype, device=pair.device)
+    with torch.cuda.device_of(pair):
+        check(lib().fn2_warp_diff_norm(_p(pair), _p(flow), _p(out), B, C2 // 2, H, W, 1 if bilinear else 0, _stream(pair)), "fn2_warp_diff_norm")
+    return out
+
+
+def warp_diff_norm_backward(pair, flow, norm, grad_norm, bilinear=True):
+    import torch
+    B, C2, H, W = pair.shape
+    assert pair.is_contiguous() and flow.is_contiguous() and norm.is_contiguous() and grad_norm.is_contiguous()
+    gflow = torch.full_like(flow, float("nan"))
+    with torch.cuda.device_of(pair):
+        check(lib().fn2_warp_diff_norm_backward(_p(pair), _p(flow), _p(norm), _p(grad_norm), _p(gflow), B, C2 // 2, H, W,
+                                                1 if bilinear else 0, _stream(pair)), "fn2_warp_diff_norm_backward")
+    return gflow
 
 
 def multiscale_l1_epe(outputs, target, weights, start_scale=4, div_flow=0.05, want_grads=False, grad_scale=1.0, norm=1):

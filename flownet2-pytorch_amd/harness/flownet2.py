@@ -16,7 +16,7 @@ from torch import nn
 
 from networks.channelnorm_package.channelnorm import ChannelNorm
 from networks.correlation_package.correlation import Correlation, CorrelationLeakyReLUCat
-from networks.resample2d_package.resample2d import Resample2d, WarpDiffNormCat
+from networks.resample2d_package.resample2d import Resample2d, WarpDiffNorm, WarpDiffNormCat
 
 
 def _conv(cin, cout, k=3, s=1):                    # submodules.conv without batch norm
@@ -189,6 +189,7 @@ class FlowNet2(nn.Module):
         self.upsample3 = nn.Upsample(scale_factor=4, mode="nearest")
         self.upsample4 = nn.Upsample(scale_factor=4, mode="nearest")
         self.warp_cat = WarpDiffNormCat(div_flow=self.div_flow)
+        self.warp_err = WarpDiffNorm()
         self.fused_training = True
 
     def _warp_concat(self, x, flow, resample):
@@ -203,8 +204,11 @@ class FlowNet2(nn.Module):
         return torch.cat((x.float(), warped, flow.float() / self.div_flow, norm), 1).to(dt)
 
     def _warp_error(self, x, flow, resample):
-        """models.py:157-161 / :170-174: (||flow||, ||first image - second image warped by flow||)."""
+        """models.py:157-161 / :170-174: (||flow||, ||first image - second image warped by flow||) -- the second as one kernel
+        (WarpDiffNorm, differentiable w.r.t. the flow); `fused_training = False` composes the separate layers."""
         f = flow.float()
+        if not torch.is_grad_enabled() or self.fused_training:
+            return self.channelnorm(f).to(x.dtype), self.warp_err(x.float(), f).to(x.dtype)
         warped = resample(x[:, 3:].float(), f)
         return self.channelnorm(f).to(x.dtype), self.channelnorm(x[:, :3].float() - warped).to(x.dtype)
 

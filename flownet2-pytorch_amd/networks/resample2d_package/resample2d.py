@@ -95,3 +95,40 @@ class WarpDiffNormCat(nn.Module):
 
     def forward(self, x, flow):
         return WarpDiffNormCatFunction.apply(x, flow, float(self.div_flow), self.bilinear)
+
+
+class WarpDiffNormFunction(Function):
+    """models.py:157-161 / :170-174 as one differentiable op: ``ChannelNorm(x[:, :3] - Resample2d(x[:, 3:], flow))``.  Forward = the fused
+    kernel storing only the norm plane; backward w.r.t. the flow = one gather-only kernel that recomputes the warp
+    (fn2_warp_diff_norm_backward).  When the image pair itself needs a gradient the unfused layers are composed under autograd."""
+
+    @staticmethod
+    def forward(ctx, x, flow, bilinear):
+        x, flow = x.contiguous(), flow.contiguous()
+        norm = resample2d_cuda.warp_diff_norm(x, flow, bool(bilinear))
+        ctx.save_for_backward(x, flow, norm)
+        ctx.bilinear = bool(bilinear)
+        return norm
+
+    @staticmethod
+    def backward(ctx, grad_norm):
+        x, flow, norm = ctx.saved_tensors
+        grad_flow = resample2d_cuda.warp_diff_norm_backward(x, flow, norm, grad_norm.contiguous(), ctx.bilinear) if ctx.needs_input_grad[1] else None
+        return None, grad_flow, None
+
+
+class WarpDiffNorm(nn.Module):
+    """``||x[:, :C] - warp(x[:, C:], flow)||_2`` (B x 1 x H x W): the brightness error FlowNet2 feeds its fusion network
+    (models.py:157-161, :170-174) in one kernel pass instead of Resample2d + subtraction + ChannelNorm."""
+
+    def __init__(self, bilinear=True):
+        super().__init__()
+        self.bilinear = bilinear
+
+    def forward(self, x, flow):
+        if x.requires_grad and torch.is_grad_enabled():
+            # the pair itself wants a gradient (not the case in FlowNet2, where it is the input): the unfused layers under autograd
+            from networks.channelnorm_package.channelnorm import ChannelNormFunction
+            c = x.shape[1] // 2
+            return ChannelNormFunction.apply(x[:, :c] - Resample2dFunction.apply(x[:, c:], flow, 1, self.bilinear), 2)
+        return WarpDiffNormFunction.apply(x, flow, self.bilinear)

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-/* 2 (round 5): + fn2_multiscale_loss, fn2_warp_diff_norm_cat_backward.  Additive: every version-1 entry point keeps its
+/* 2 (round 5): + fn2_multiscale_loss, fn2_warp_diff_norm_cat_backward, fn2_warp_diff_norm,
+ * fn2_warp_diff_norm_backward.  Additive: every version-1 entry point keeps its
  * signature and meaning; a caller built against version 1 runs unchanged on a version-2 library. */
 #define FN2_ABI_VERSION 2
 
@@ -222,6 +223,18 @@ int fn2_warp_diff_norm_cat(const float *pair, const float *flow, float *out, flo
 int fn2_warp_diff_norm_cat_backward(const float *pair, const float *flow, const float *out_cat, const float *grad_cat,
                                     float *grad_pair, float *grad_flow, float div_flow, int B, int C, int H, int W,
                                     int bilinear, void *stream);
+
+/* Row N2 without the concat -- the other two warp sites of FlowNet2 (models.py:157-161, :170-174):
+ *   out_norm = ChannelNorm(pair[:, :C] - Resample2d(pair[:, C:], flow))      B x 1 x H x W, fully written
+ * by the kernel of fn2_warp_diff_norm_cat storing only the norm plane (bit-identical to that plane), and its backward with respect
+ * to the flow: g_warped = -grad_norm * diff / (norm + 1e-9) (channelnorm_kernel.cu:93) fed to the gather of the Resample2d backward
+ * (resample2d_kernel.cu:127-198); the warped image is not stored by the forward and is recomputed from the same corners with the
+ * forward's arithmetic (`bilinear` must be the forward's).  grad_flow: B x 2 x H x W, fully written, bit-identical to autograd
+ * through the unfused entry points.  The pair gets no gradient here (it is the network's input in FlowNet2): compose
+ * fn2_channelnorm_backward and fn2_resample2d_backward when it needs one.  float32, kernel_size 1.  (ABI v2) */
+int fn2_warp_diff_norm(const float *pair, const float *flow, float *out_norm, int B, int C, int H, int W, int bilinear, void *stream);
+int fn2_warp_diff_norm_backward(const float *pair, const float *flow, const float *norm, const float *grad_norm, float *grad_flow,
+                                int B, int C, int H, int W, int bilinear, void *stream);
 
 /* "Next" row N3: the training loss of FlowNet2 -- MultiScale with the L1 norm (losses.py:52-86) -- and
  * the EPE metric (losses.py:11-12) in one pass over the target flow instead of five AvgPool2d passes and ~35 launches.

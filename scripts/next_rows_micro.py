@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "flownet2-pytorch_amd"))
 import torch
 import torch.nn.functional as F
 from networks.correlation_package.correlation import Correlation, CorrelationLeakyReLUCat
-from networks.resample2d_package.resample2d import Resample2d, WarpDiffNormCat
+from networks.resample2d_package.resample2d import Resample2d, WarpDiffNorm, WarpDiffNormCat
 from networks.channelnorm_package.channelnorm import ChannelNorm
 
 dev = torch.device("cuda:0")
@@ -93,4 +93,16 @@ for need_x in (False, True):
     key = "N2_bwd_pair_grad_" if need_x else "N2_bwd_flow_only_"
     res[key + "unfused_us"] = timeit(lambda: unf.backward(gcat, retain_graph=True))
     res[key + "fused_us"] = timeit(lambda: fus.backward(gcat, retain_graph=True))
+# N2 without the concat (models.py:157-161, :170-174): ||first image - warped|| and its flow gradient
+we = WarpDiffNorm()
+gn = torch.randn(8, 1, 384, 512, generator=g).to(dev)
+with torch.no_grad():
+    res["N2n_unfused_us"] = timeit(lambda: cn(x[:, :3] - rs(x[:, 3:], flow)))
+    res["N2n_fused_us"] = timeit(lambda: we(x, flow))
+fl = flow.clone().requires_grad_(True)
+unf = cn(x[:, :3] - rs(x[:, 3:], fl))
+fl2 = flow.clone().requires_grad_(True)
+fus = we(x, fl2)
+res["N2n_bwd_unfused_us"] = timeit(lambda: unf.backward(gn, retain_graph=True))
+res["N2n_bwd_fused_us"] = timeit(lambda: fus.backward(gn, retain_graph=True))
 print(json.dumps(res))

@@ -54,7 +54,7 @@ def graded_corr_inputs(fixture):
     """Inputs of tests/golden/corrgraded_*.npz: not stored, regenerated from the fixture's seed exactly as
     tests/golden/make_golden_corr_graded.py drew them; the stored checksum tells a different numpy generator from a wrong result."""
     B, C, H, W = (int(v) for v in fixture["shape"])
-    rng = np.random.default_rng(int(fixture["seed"]))
+    rng = np.random.default_rng(int(fixture["seed"]))          # (the stored seed is the generator's SEED + C)
     in1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
     in2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
     gout = rng.standard_normal((B, 441, H, W)).astype(np.float32)

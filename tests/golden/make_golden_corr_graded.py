@@ -5,7 +5,7 @@ group, neighbour row block) pair, ragged displacement ranges at all four borders
 The reference's device code runs under the CPU SIMT shim (one fibre per CUDA thread): about four minutes for this case.
     python tests/golden/make_golden_corr_graded.py
 
-To keep the fixture small the inputs are NOT stored: they are the first draws of numpy's default_rng(SEED) (in1, in2, gout, in
+To keep the fixture small the inputs are NOT stored: they are the first draws of numpy's default_rng(seed_of(C)) (in1, in2, gout, in
 this order, standard normal, float32; two channels of in1 / in2 rescaled as in make_golden_corr_f16x2.py), and the fixture holds a
 checksum of them so that a test can tell a different generator from a wrong kernel.  Of the reference's results it keeps
   out    : 32 of the 441 displacement planes in full (PLANES: the four corners, the centre, the band edges, a spread of the rest)
@@ -24,13 +24,19 @@ from oracle.oracle import Oracle  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 20260924
-B, C, H, W = 1, 64, 48, 64
+# (name suffix, B, C, H, W): 64 channels = the smallest channel count the kernels take (two 32-channel steps, one 64-channel group);
+# 256 channels = FlowNetC's conv3 (eight steps of the forward, four channel-group tasks per row group in the backward; ~20 minutes)
+CASES = [("1x64x48x64", 1, 64, 48, 64), ("1x256x48x64", 1, 256, 48, 64)]
 PLANES = sorted(set([0, 20, 420, 440, 220, 10, 210, 230, 430, 21, 41, 399, 419] + list(range(7, 441, 23))))[:32]
 CHANNELS = [0, 3, 7, 17, 31, 32, 48, 63]
 
 
-def make_inputs():
-    rng = np.random.default_rng(SEED)
+def seed_of(C):
+    return SEED if C == 64 else SEED + C      # (the 64-channel fixture was drawn from SEED itself)
+
+
+def make_inputs(B, C, H, W):
+    rng = np.random.default_rng(seed_of(C))
     in1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
     in2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
     gout = rng.standard_normal((B, 441, H, W)).astype(np.float32)
@@ -43,8 +49,16 @@ def checksum(*arrays):
 
 
 def main():
+    only = sys.argv[1:]
+    for name, B, C, H, W in CASES:
+        if not only or name in only:
+            one(name, B, C, H, W)
+
+
+def one(name, B, C, H, W):
     ref = Oracle(ref=True)
-    in1, in2, gout = make_inputs()
+    in1, in2, gout = make_inputs(B, C, H, W)
+    channels = CHANNELS if C == 64 else [0, 3, 7, 63, 64, 130, 200, 255]
     pad, k, md, s1, s2 = 20, 1, 20, 1, 2        # FlowNetC.py:28
     t = time.time()
     out = ref.corr_fwd(in1, in2, pad, k, md, s1, s2)
@@ -53,13 +67,13 @@ def main():
     g1, g2 = ref.corr_bwd(in1, in2, gout, pad, k, md, s1, s2)
     print("backward %.0f s" % (time.time() - t), flush=True)
     o64 = out.astype(np.float64)
-    d = dict(seed=np.int64(SEED), shape=np.array([B, C, H, W], np.int32), params=np.array([pad, k, md, s1, s2], np.int32),
-             input_checksum=checksum(in1, in2, gout), planes=np.array(PLANES, np.int32), channels=np.array(CHANNELS, np.int32),
+    d = dict(seed=np.int64(seed_of(C)), shape=np.array([B, C, H, W], np.int32), params=np.array([pad, k, md, s1, s2], np.int32),
+             input_checksum=checksum(in1, in2, gout), planes=np.array(PLANES, np.int32), channels=np.array(channels, np.int32),
              out_planes=out[:, PLANES], out_sum=o64.sum(axis=(0, 2, 3)), out_sumsq=(o64 * o64).sum(axis=(0, 2, 3)),
-             g1_channels=g1[:, CHANNELS], g2_channels=g2[:, CHANNELS],
+             g1_channels=g1[:, channels], g2_channels=g2[:, channels],
              g1_sum=g1.astype(np.float64).sum(axis=(0, 2, 3)), g2_sum=g2.astype(np.float64).sum(axis=(0, 2, 3)),
              g1_abs=np.abs(g1.astype(np.float64)).sum(axis=(0, 2, 3)), g2_abs=np.abs(g2.astype(np.float64)).sum(axis=(0, 2, 3)))
-    path = os.path.join(OUT, "corrgraded_1x64x48x64.npz")
+    path = os.path.join(OUT, f"corrgraded_{name}.npz")
     np.savez_compressed(path, **d)
     print(path, os.path.getsize(path), "bytes")
 

@@ -83,6 +83,11 @@ def test_rejected_calls_return_codes_without_gpu():
     assert wb(p, p, p, p, null, null, f32(20.0), 1, 3, 8, 8, 1, null) == -1        # no flow gradient to write
     assert wb(p, p, p, p, null, p, f32(20.0), 0, 3, 8, 8, 1, null) == 0            # empty batch
     assert wb(mis, p, p, p, null, p, f32(20.0), 1, 3, 8, 8, 1, null) == -3         # FN2_EALIGN
+    assert lib.fn2_warp_diff_norm(p, p, null, 1, 3, 8, 8, 1, null) == -1                    # no output
+    assert lib.fn2_warp_diff_norm(p, p, p, 1, 0, 8, 8, 1, null) == -1                       # C < 1
+    assert lib.fn2_warp_diff_norm(p, p, p, 0, 3, 8, 8, 1, null) == 0                        # empty batch
+    assert lib.fn2_warp_diff_norm_backward(p, p, p, null, p, 1, 3, 8, 8, 1, null) == -1     # no gradient of the norm
+    assert lib.fn2_warp_diff_norm_backward(p, p, mis, p, p, 1, 3, 8, 8, 1, null) == -3      # FN2_EALIGN
     outs = (ctypes.c_void_p * 1)(p.value)
     w1 = (ctypes.c_float * 1)(0.32)
     ml = lib.fn2_multiscale_loss

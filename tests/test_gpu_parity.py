@@ -381,6 +381,51 @@ def test_warp_diff_norm_cat_backward(dev, oracle, shape, bilinear):
         assert max_abs(x2.grad[:, C:].cpu().numpy(), gn[:, C:2 * C] + rimg) <= 2e-5 * max(1.0, float(np.abs(rimg).max()))
 
 
+@pytest.mark.parametrize("shape", [(8, 3, 384, 512), (2, 3, 40, 64), (3, 3, 50, 132), (2, 2, 17, 33), (1, 1, 16, 36), (1, 3, 100, 200)])
+@pytest.mark.parametrize("bilinear", [True, False])
+def test_warp_diff_norm(dev, oracle, shape, bilinear):
+    """Row N2 without the concat (models.py:157-161, :170-174): ||first image - warped second image|| as one kernel, and its flow
+    gradient as one gather-only kernel that RECOMPUTES the warp (the forward stores only the norm) -- both bit-identical to the unfused
+    HIP layers under autograd (Resample2d, subtraction, ChannelNorm), bilinear and nearest sampling, tiled and untiled shapes; a
+    translated flow (windows that follow it); on a small case against the oracle's composition of the reference kernels."""
+    import fn2_capi
+    from networks.resample2d_package.resample2d import Resample2d, WarpDiffNorm
+    from networks.channelnorm_package.channelnorm import ChannelNorm
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(7 * B + C + H + W)
+    x0 = torch.randn(B, 2 * C, H, W, generator=g)
+    for shift in (0.0, 21.0):
+        f0 = _flow(g, (B, 2, H, W), 4.0)
+        f0[:, 0] += shift; f0[:, 1] -= 0.6 * shift
+        gn = torch.randn(B, 1, H, W, generator=g).to(dev)
+        x, f = x0.to(dev), f0.to(dev).requires_grad_(True)
+        res = Resample2d(1, bilinear)(x[:, C:], f)
+        unf = ChannelNorm()(x[:, :C] - res)
+        unf.backward(gn)
+        f2 = f0.to(dev).requires_grad_(True)
+        out = WarpDiffNorm(bilinear)(x, f2)
+        assert torch.equal(out, unf.detach())
+        out.backward(gn)
+        assert torch.equal(f2.grad, f.grad), float((f2.grad - f.grad).abs().max())
+        # the C ABI through ctypes (outputs start as NaN)
+        n2 = fn2_capi.warp_diff_norm(x, f0.to(dev), bilinear)
+        assert torch.equal(n2, unf.detach())
+        assert torch.equal(fn2_capi.warp_diff_norm_backward(x, f0.to(dev), n2, gn, bilinear), f.grad)
+    # a pair that wants a gradient takes the unfused layers under autograd: same values
+    xg, fg = x0.to(dev).requires_grad_(True), f0.to(dev).requires_grad_(True)
+    WarpDiffNorm(bilinear)(xg, fg).backward(gn)
+    assert torch.equal(fg.grad, f.grad) and xg.grad is not None and float(xg.grad.abs().max()) > 0
+    if B * C * H * W <= 3 * 3 * 50 * 132:
+        xn, fn, gnn = x0.numpy(), f0.numpy(), gn.cpu().numpy()
+        warped = oracle.resample_fwd(np.ascontiguousarray(xn[:, C:]), fn, 1, bilinear)
+        diff = xn[:, :C] - warped
+        nrm = oracle.chnorm_fwd(diff)
+        assert max_abs(out.detach().cpu().numpy(), nrm) <= 1e-6 * max(1.0, float(nrm.max()))
+        gdiff = oracle.chnorm_bwd(diff, nrm, gnn)
+        _, rflow = oracle.resample_bwd(np.ascontiguousarray(xn[:, C:]), fn, np.ascontiguousarray(-gdiff), 1, True)
+        assert max_abs(f2.grad.cpu().numpy(), rflow) <= 1e-5 * max(1.0, float(np.abs(rflow).max()))
+
+
 def test_resample2d_rejects_non_float(dev):
     import resample2d_cuda
     a = torch.zeros(1, 3, 8, 8, device=dev, dtype=torch.float64)
