@@ -137,14 +137,28 @@ class HotPath:
             a.grad = b.grad = img1.grad = flow.grad = None
             corr(a, b).backward(self.gcorr)
             norm(img0 - warp(img1, flow)).backward(self.gnorm)
-        for _ in range(3):
-            one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        # the same statements through the fused row FlowNet2 actually runs at its warp sites (models.py:157-161: the image pair is
+        # the network's input and gets no gradient): WarpDiffNorm, one kernel forward, one gather-only kernel backward
+        from networks.resample2d_package.resample2d import WarpDiffNorm
+        werr = WarpDiffNorm()
+        pair = torch.cat((img0, self.img), 1)
+        flow2 = self.flow.clone().requires_grad_(True)
+
+        def one_fused():
+            a.grad = b.grad = flow2.grad = None
+            corr(a, b).backward(self.gcorr)
+            werr(pair, flow2).backward(self.gnorm)
+
+        def clock(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        return clock(one), clock(one_fused)
 
 
 def cpu_baseline(max_seconds=30.0):
@@ -636,7 +650,7 @@ def main():
 
     # The same step through the shipped autograd wrappers (Correlation / Resample2d / ChannelNorm modules, with the
     # difference op of models.py:135 between warp and norm): what a training script pays, allocations included.
-    mod_elapsed = hp.module_steps(args.steps)
+    mod_elapsed, mod_fused_elapsed = hp.module_steps(args.steps)
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
@@ -771,6 +785,7 @@ def main():
             "launch": "hipGraph replay of the step" if graph is not None else "eager launches",
             "ms_per_step_eager_with_events": round(eager_elapsed / args.steps * 1e3, 4),
             "ms_per_step_autograd_modules": round(mod_elapsed / args.steps * 1e3, 4),
+            "ms_per_step_autograd_fused_rows": round(mod_fused_elapsed / args.steps * 1e3, 4),   # Correlation + WarpDiffNorm (flow gradient only)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
