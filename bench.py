@@ -212,7 +212,7 @@ def cpu_baseline(max_seconds=30.0):
 
 
 # ---- a second CPU formulation of the same step (SURVEY.md 8d "no sandbagging"): whole-array PyTorch at torch's fastest thread
-# count on the host (16 of 256 cores; NOT faster than the OpenMP oracle on all cores: 12.9 against 13.7 pairs/s in round 5) -- 441 shifted channel contractions with EXPLICIT backward passes for the correlation, grid_sample (border,
+# count on the host (16 of 256 cores; NOT faster than the OpenMP oracle on all cores: 12.9-15.4 against 13.7-15.9 pairs/s in round 5) -- 441 shifted channel contractions with EXPLICIT backward passes for the correlation, grid_sample (border,
 # align_corners: the closed form of resample2d_kernel.cu:15-72) and its autograd for the warp, the L2 norm
 # and its closed-form gradient.  Tolerance-level equal to the oracle (tests/test_bench_cpu_fast.py), not bit-exact: the
 # summation order is whatever the vectorised kernels choose.
