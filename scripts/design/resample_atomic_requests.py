@@ -1,3 +1,8 @@
+"""Cost model of the Resample2d backward's global atomics (scripts/ubench/atomic_rate.hip): fp32 atomics cost per REQUEST
+= per aligned 64-byte segment one instruction touches, 20.5 G requests/s chip-wide.  For the bench's flow (image 0 x 8) and a tile shape
+(TH, TW, R): pixels whose corners leave the window (12 single-lane atomics each today, half with the two corners of a row in one request)
+and the 16-float segments of the window rows that receive a non-zero contribution (x 3 channels).  tests/test_tiling_model.py ties
+the 32 x 64 +- 16 row to the numbers the document quotes."""
 import numpy as np, torch
 g = torch.Generator().manual_seed(0)
 B, C, H, W = 8, 3, 384, 512

@@ -140,3 +140,25 @@ def test_task_table_limits_in_sources():
     m = re.search(r"constexpr int MAX_TAB = (\d+);", s)
     assert m and int(m.group(1)) == 768            # 2 parities x NRG x 6 row blocks <= 768  ->  H <= 512
     assert 2 * ((512 // 2 + 3) // 4) * 6 == 768
+
+
+def test_resample_backward_atomic_request_model():
+    """DESIGN.md 4.6's cost model of the Resample2d backward (scripts/design/resample_atomic_requests.py): global fp32 atomics cost per
+    REQUEST = per aligned 64-byte segment an instruction touches.  Brute force on a small field: the model's count of flush segments equals
+    the number of distinct (tile, plane row, 16-float segment) triples that receive a non-zero contribution, and for the bench's flow the
+    model gives the 0.59 M + 0.20 M requests the document quotes."""
+    import importlib.util
+    import os
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("req", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "design",
+                                                                       "resample_atomic_requests.py"))
+    src = open(spec.origin).read().split("for shape in (")[0]          # the definitions, not the table it prints
+    ns = {}
+    exec(compile(src, spec.origin, "exec"), ns)
+    r = ns["count"](32, 64, 16, b=0)
+    flush, far_now, far_px = r["flush_req"] * 8, r["far_req_now"] * 8, r["far_px"] * 8
+    assert 0.55e6 < flush < 0.63e6 and 0.18e6 < far_now < 0.23e6 and 16e3 < far_px < 21e3
+    assert r["far_req_merged"] < 0.6 * r["far_req_now"]                 # two corners of a row in one request: about half
+    # at 20.5 G requests/s: 36-42 us of atomic-unit time
+    assert 36.0 < (flush + far_now) / 20.5e3 < 42.0
