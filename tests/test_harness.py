@@ -332,15 +332,21 @@ def test_flownet2_trains_through_the_fused_warp(dev):
         assert torch.isfinite(out).all()
     assert grads["fused"].keys() == grads["unfused"].keys() and len(grads["fused"]) > 100
 
+    def rel_l2(a, b):
+        num = sum(float(((a[n] - b[n]).double() ** 2).sum()) for n in a) ** 0.5
+        return num / sum(float((b[n].double() ** 2).sum()) for n in a) ** 0.5
+
     def worst(a, b):
         return max(float((a[n] - b[n]).abs().max()) / max(float(b[n].abs().max()), 1e-12) for n in a)
-    # the forward is bit-identical and so is grad_flow; what differs from run to run is the order of MIOpen's own reductions in the
-    # convolution backward passes (atomics), amplified through five stacked networks: the bar is that run-to-run noise, measured here
-    noise = worst(grads["unfused again"], grads["unfused"])
-    diff = worst(grads["fused"], grads["unfused"])
-    # (about one run in fifteen MIOpen picks another algorithm for one of the convolution backward passes in the pass with the fewer
-    # temporaries -- its choice depends on the allocator's state --: 1.4e-3 against a run-to-run noise of 2e-5 on that box.  What the
-    # fused rows themselves contribute is pinned bit for bit at the layer boundary: test_warp_diff_norm_cat_backward, test_warp_diff_norm.)
-    assert diff <= max(5e-3, 4.0 * noise), (diff, noise)
+    # The forward of this network is not bit-reproducible from pass to pass (MIOpen), and a bilinear warp's gradient jumps where a
+    # sample crosses an integer coordinate: now and then ONE pixel flips between two passes and a small bias gradient moves by up to
+    # 0.8 % -- between two unfused passes as often as between a fused and an unfused one (scripts/fused_training_probe.py).  The bar is
+    # therefore the relative L2 distance over ALL parameter gradients (1.6-2.5e-7 between any two passes, 4e-7 with a flip; a wrong
+    # fused backward would show at 1e-2), with the per-parameter maximum as a loose second check.  What the fused rows themselves
+    # contribute is pinned bit for bit at the layer boundary: test_warp_diff_norm_cat_backward, test_warp_diff_norm.
+    noise = rel_l2(grads["unfused again"], grads["unfused"])
+    diff = rel_l2(grads["fused"], grads["unfused"])
+    assert diff <= max(1e-5, 10.0 * noise), (diff, noise)
+    assert worst(grads["fused"], grads["unfused"]) <= 5e-2
     grads = {True: grads["fused"]}
     assert any(float(g.abs().max()) > 0 for n, g in grads[True].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp
