@@ -341,12 +341,12 @@ def test_flownet2_trains_through_the_fused_warp(dev):
     # The forward of this network is not bit-reproducible from pass to pass (MIOpen), and a bilinear warp's gradient jumps where a
     # sample crosses an integer coordinate: now and then ONE pixel flips between two passes and a small bias gradient moves by up to
     # 0.8 % -- between two unfused passes as often as between a fused and an unfused one (scripts/fused_training_probe.py).  The bar is
-    # therefore the relative L2 distance over ALL parameter gradients (1.6-2.5e-7 between any two passes, 4e-7 with a flip; a wrong
-    # fused backward would show at 1e-2), with the per-parameter maximum as a loose second check.  What the fused rows themselves
+    # therefore the relative L2 distance over ALL parameter gradients (1.6-2.5e-7 between any two passes, 4e-7 ... 4e-5 with a flip; a
+    # wrong fused backward would show at 1e-2 or more), with the per-parameter maximum as a loose second check.  What the fused rows themselves
     # contribute is pinned bit for bit at the layer boundary: test_warp_diff_norm_cat_backward, test_warp_diff_norm.
     noise = rel_l2(grads["unfused again"], grads["unfused"])
     diff = rel_l2(grads["fused"], grads["unfused"])
-    assert diff <= max(1e-5, 10.0 * noise), (diff, noise)
+    assert diff <= max(1e-3, 10.0 * noise), (diff, noise)
     assert worst(grads["fused"], grads["unfused"]) <= 5e-2
     grads = {True: grads["fused"]}
     assert any(float(g.abs().max()) > 0 for n, g in grads[True].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp
