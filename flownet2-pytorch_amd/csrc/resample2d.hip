@@ -606,8 +606,13 @@ __global__ __launch_bounds__(TH * 16, (2 * TH * 16 + 255) / 256) void resample_f
 template <int TH, int TW, int R, int NC, int WPE = 4, int NTH = 1024>
 __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *__restrict__ img, ImgStrides is,
                                                                 const float *__restrict__ flow, float *__restrict__ out,
-                                                                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int bilinear)
+                                                                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int bilinear,
+                                                                unsigned long long *dbg = nullptr)
 {
+    // profiling (debug library, flag 0x10000): wall-clock stamps (100 MHz) of the workgroup's phases
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int i) __attribute__((always_inline)) { if (dbg) ts[i] = wall_clock64(); };
+    stamp(0);
     constexpr int NT = NTH, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
     static_assert(TH * TW % NT == 0, "whole pixels per thread");
     __shared__ __attribute__((aligned(16))) float win[NC][WH * WW];
@@ -647,7 +652,9 @@ __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *
             const int i = tid + NT * j;
             if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(&win[c][4 * i]) = wreg[c][j];
         }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
@@ -695,6 +702,13 @@ __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *
             }
             store_out(out + ((long)b * NC + c) * HW + (y * W + x), val);
         }
+    }
+    if (dbg && tid == 0) {
+        stamp(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
+        unsigned long long *d = dbg + (long)blockIdx.x * 8;
+        for (int i = 0; i < 5; ++i) d[i] = ts[i];
     }
 }
 
@@ -1512,8 +1526,12 @@ static int resample2d_forward_impl(const float *img, const int64_t *img_strides,
             // CU), one barrier in the whole kernel, corner offsets and weights formed once per pixel -- 8 x 3 x 384 x 512: 19.3 us
             // against 20.9 for the per-channel kernel (smooth flow 18.1 / 19.1), same bits
             const int tiles_y = (H + 31) / 32;
+            unsigned long long *dbgbuf = nullptr;
+#ifdef FN2_DEBUG_BUILD
+            if (bilinear & 0x10000) dbgbuf = static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer());
+#endif
             hipLaunchKernelGGL((resample_fwd_tiled_all<32, TW, 16, 3, 8>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024), 0, s,
-                               img, is, flow, out, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0);
+                               img, is, flow, out, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0, dbgbuf);
             return launch_status();
         }
         const int th = (bilinear >> 12) & 3 ? ((bilinear >> 12) & 3) == 1 ? 48 : 32 : tile_height(B, H, tiles_x);
