@@ -603,25 +603,19 @@ __global__ __launch_bounds__(TH * 16, (2 * TH * 16 + 255) / 256) void resample_f
 // Forward with ALL image channels of the window resident in LDS (C == NC, typically 3): a workgroup owns a TH x TW tile,
 // loads the NC windows at once (one barrier in the whole kernel instead of one per channel), forms the corner offsets and the
 // double-precision weights once per pixel and gathers the NC channels back to back.
-template <int TH, int TW, int R, int NC, int WPE = 4, int NTH = 1024>
-__global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *__restrict__ img, ImgStrides is,
-                                                                const float *__restrict__ flow, float *__restrict__ out,
-                                                                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int bilinear,
-                                                                unsigned long long *dbg = nullptr)
+// One tile of the all-channel forward: rows [Y0, Y0 + TH) x columns [X0, X0 + TW) of item b; `win` holds NC windows of
+// (TH + 2R) x (TW + 2R) floats.  The caller provides the barrier before `win` is reused.
+template <int TH, int TW, int R, int NC, int NT>
+__device__ __forceinline__ void fwd_tile_all(float *__restrict__ win, const float *__restrict__ img, const ImgStrides is,
+                                             const float *__restrict__ flow, float *__restrict__ out, int Hi, int Wi, int H, int W,
+                                             int b, int X0, int Y0, int ylim, int bilinear, unsigned long long *ts = nullptr)
 {
-    // profiling (debug library, flag 0x10000): wall-clock stamps (100 MHz) of the workgroup's phases
-    unsigned long long ts[5] = {0, 0, 0, 0, 0};
-    auto stamp = [&](int i) __attribute__((always_inline)) { if (dbg) ts[i] = wall_clock64(); };
-    stamp(0);
-    constexpr int NT = NTH, WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
+    // `ts` (profiling, debug library): four wall-clock stamps (100 MHz) -- entry, windows written to LDS, barrier, stores issued
+    constexpr int WH = TH + 2 * R, WW = TW + 2 * R, PPT = TH * TW / NT, NW = (WH * (WW / 4) + NT - 1) / NT;
     static_assert(TH * TW % NT == 0, "whole pixels per thread");
-    __shared__ __attribute__((aligned(16))) float win[NC][WH * WW];
     const int tid = threadIdx.x;
-    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int X0 = tx * TW, Y0 = ty * TH, wx0 = X0 - R, wy0 = Y0 - R;
+    if (ts) ts[0] = wall_clock64();
+    const int wx0 = X0 - R, wy0 = Y0 - R;
     const long HW = (long)H * W;
     // the flow of the thread's pixels and every window group: all requested before anything is used
     float fdx[PPT], fdy[PPT];
@@ -629,7 +623,7 @@ __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        const long p = (x < W && y < H) ? (long)y * W + x : 0;
+        const long p = (x < W && y < ylim) ? (long)y * W + x : 0;
         fdx[k] = flow[(long)b * 2 * HW + p]; fdy[k] = flow[(long)b * 2 * HW + HW + p];
     }
     f4 wreg[NC][NW];
@@ -650,16 +644,16 @@ __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int i = tid + NT * j;
-            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(&win[c][4 * i]) = wreg[c][j];
+            if (i < WH * (WW / 4)) *reinterpret_cast<f4 *>(win + c * (WH * WW) + 4 * i) = wreg[c][j];
         }
-    stamp(1);
+    if (ts) ts[1] = wall_clock64();
     __syncthreads();
-    stamp(2);
+    if (ts) ts[2] = wall_clock64();
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int idx = tid + NT * k;
         const int x = X0 + idx % TW, y = Y0 + idx / TW;
-        if (!((x < W) && (y < H))) continue;
+        if (!((x < W) && (y < ylim))) continue;
         const float xf = (float)x + fdx[k], yf = (float)y + fdy[k];
         int xL, xR, yT, yB;
         float alpha = 0.0f, beta = 0.0f;
@@ -684,7 +678,7 @@ __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *
         for (int c = 0; c < NC; ++c) {
             float i00, i01, i10, i11;
             if (in) {
-                const float *wc = win[c];
+                const float *wc = win + c * (WH * WW);
                 i00 = wc[o]; i01 = wc[o + ox]; i10 = wc[o + oy]; i11 = wc[o + oy + ox];
             } else {
                 const float *I = img + (long)b * is.b + (long)c * is.c;
@@ -703,12 +697,26 @@ __global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *
             store_out(out + ((long)b * NC + c) * HW + (y * W + x), val);
         }
     }
-    if (dbg && tid == 0) {
-        stamp(3);
+    if (ts) ts[3] = wall_clock64();
+}
+
+template <int TH, int TW, int R, int NC, int WPE = 4, int NTH = 1024>
+__global__ __launch_bounds__(NTH, WPE) void resample_fwd_tiled_all(const float *__restrict__ img, ImgStrides is,
+                                                                const float *__restrict__ flow, float *__restrict__ out,
+                                                                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int bilinear,
+                                                                unsigned long long *dbg = nullptr)
+{
+    __shared__ __attribute__((aligned(16))) float win[NC * (TH + 2 * R) * (TW + 2 * R)];
+    int t = (int)xcd_remap(blockIdx.x, gridDim.x);   // an XCD's workgroups take consecutive tiles: neighbours share its L2
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    unsigned long long ts[4] = {0, 0, 0, 0};
+    fwd_tile_all<TH, TW, R, NC, NTH>(win, img, is, flow, out, Hi, Wi, H, W, t / tiles_y, tx * TW, ty * TH, H, bilinear, dbg ? ts : nullptr);
+    if (dbg && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(4);
         unsigned long long *d = dbg + (long)blockIdx.x * 8;
-        for (int i = 0; i < 5; ++i) d[i] = ts[i];
+        for (int i = 0; i < 4; ++i) d[i] = ts[i];
+        d[4] = wall_clock64();
     }
 }
 
@@ -1528,8 +1536,10 @@ static int resample2d_forward_impl(const float *img, const int64_t *img_strides,
             const int tiles_y = (H + 31) / 32;
             unsigned long long *dbgbuf = nullptr;
 #ifdef FN2_DEBUG_BUILD
-            if (bilinear & 0x10000) dbgbuf = static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer());
+            if (bilinear & 0x10000) dbgbuf = static_cast<unsigned long long *>(corr_f16x2_get_debug_buffer());   // profiling: timeline stamps
 #endif
+            // (512 persistent workgroups taking one tile and then half of one of the remaining 256 -- one balanced round instead of one
+            // and a half -- measured slower: 18.6 us against 17.0, the half tile costs 4.8 us of fixed latencies)
             hipLaunchKernelGGL((resample_fwd_tiled_all<32, TW, 16, 3, 8>), dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(1024), 0, s,
                                img, is, flow, out, Hi, Wi, H, W, tiles_x, tiles_y, (bilinear & 1) ? 1 : 0, dbgbuf);
             return launch_status();

@@ -45,19 +45,29 @@ for flags, name in ((0x10000, "full kernel"), (0x10200, "no flush"), (0x10400, "
     print("   workgroups between 'scatter done' and 'windows staged' (flush in progress) every 2 us:", busy)
 
 
-# ---- forward (resample_fwd_tiled_all): start / windows written to LDS / barrier / stores issued / queue drained
+# ---- forward (resample_fwd_tiled_all, 768 workgroups)
 out = torch.zeros_like(img)
-for fl, name in ((flow, "forward, white-noise flow"), (torch.nn.functional.avg_pool2d(torch.randn(B, 2, H, W, generator=g) * 30, 31, 1, 15).to(dev), "forward, smooth flow")):
-    stamps.zero_()
-    for _ in range(3):
-        dbg.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, 0x10000, st)
+def timeit(fn, n=40):
+    for _ in range(5): fn()
     torch.cuda.synchronize()
-    t = stamps.cpu().numpy().reshape(768, 8).astype(np.float64)
-    us = (t[:, :5] - t[:, 0].min()) / 100.0
-    first = us[:, 0] < 2.0
-    print(name, ": %d workgroups start within 2 us, the rest from %.1f us on; kernel ends at %.1f us" % (first.sum(), us[~first, 0].min(), us[:, 4].max()))
-    for grp, lab in ((first, "first round"), (~first, "second round")):
-        print("  ", lab, "(%d workgroups)" % grp.sum())
-        for i, nm in enumerate(["start", "flow + windows loaded, LDS written", "barrier", "gathers done, stores issued", "end (queue drained)"]):
-            v = us[grp, i]; d = v - us[grp, i - 1] if i else v
-            print("      %-36s at %6.1f us (min %6.1f max %6.1f)   phase %5.1f us (min %5.1f max %5.1f)" % (nm, v.mean(), v.min(), v.max(), d.mean(), d.min(), d.max()))
+    ev = []
+    for _ in range(n):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record(); fn(); e_.record(); ev.append((s_, e_))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    return ts[len(ts) // 2]
+smooth = torch.nn.functional.avg_pool2d(torch.randn(B, 2, H, W, generator=g) * 30, 31, 1, 15).to(dev)
+for fl, name in ((flow, "white-noise flow"), (smooth, "smooth flow")):
+    ref = None
+    for flags, lab, nwg in ((0, "768 tiles", 768),):
+        t_us = timeit(lambda: dbg.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags, st))
+        stamps.zero_()
+        dbg.fn2_debug_resample2d_forward(P(img), None, P(fl), P(out), B, C, H, W, H, W, 1, 1, flags | 0x10000, st)
+        torch.cuda.synchronize()
+        if ref is None: ref = out.clone()
+        t = stamps.cpu().numpy().reshape(768, 8)[:nwg].astype(np.float64)
+        us = (t[:, :5] - t[:, 0].min()) / 100.0
+        print("forward, %s, %s: %.1f us by event pair; inside the kernel %d workgroups, first tile: windows in LDS at %.1f us, barrier %.1f, stores issued %.1f; "
+              "workgroups end at %.1f us on average, the last at %.1f us;  max |d| vs the plain grid %.1e" % (
+                  name, lab, t_us, nwg, us[:, 1].mean(), us[:, 2].mean(), us[:, 3].mean(), us[:, 4].mean(), us[:, 4].max(), float((out - ref).abs().max())))
