@@ -416,10 +416,19 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
     if world > 1:
         # N ranks each running MIOpen's kernel search at once is how a scaling run ends in the watchdog: rank 0 searches first (its
         # results land in the user find database all ranks of the node share), the others then warm up against that database
+        # The staggered warm-up must be COLLECTIVE-FREE: train_step() issues the bucketed gradient all-reduces, and a
+        # rank that runs them alone while the others sit in the barrier pairs a 48 MB all-reduce with the barrier's 1-element one
+        # (undefined on RCCL, a size mismatch on gloo).  Forward + loss + backward with the reducer's collectives switched off
+        # finds the same MIOpen kernels; the optimizer's elementwise kernels need no search.
         def warm():
-            tr.train_step(inputs, target)
-            tr.infer(inputs)
-            torch.cuda.synchronize()
+            was = tr.reducer.collective
+            tr.reducer.collective = False
+            try:
+                fwd_bwd()
+                tr.infer(inputs)
+                torch.cuda.synchronize()
+            finally:
+                tr.reducer.collective = was
         sync = (lambda: torch.distributed.barrier(device_ids=[dev.index])) if torch.distributed.get_backend() == "nccl" else torch.distributed.barrier
         if rank == 0:
             warm()
@@ -456,6 +465,83 @@ def flownet2c_pass(dev, rank, world, steps, warmup):
             "fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_image_pairs_per_s": round(pairs / t_fb, 1),
             "inference_ms": round(t_inf * 1e3, 3), "inference_image_pairs_per_s": round(pairs / t_inf, 1),
             "grad_buckets": n_buckets, "parallelism": f"dp{world}: replica per GPU, bucketed all-reduce overlapped with backward"}
+
+
+def _parse_cpulist(text):
+    cores = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cores.update(range(int(lo), int(hi or lo) + 1))
+    return cores
+
+
+def rank_cpu_cores(local_rank, local_world, available, gpu_cpulists=None):
+    """The host cores rank `local_rank` of `local_world` pins itself to (pure function; tests/test_bench_launch.py).  A 0.19 ms step is
+    launched by one host thread: a rank whose thread shares a core with another rank's (or with the box's housekeeping) becomes
+    "the slowest rank" of a max-over-ranks timing.  `gpu_cpulists[d]` = the cores next to GPU d (its PCI device's local_cpulist) or
+    None: ranks whose GPUs sit on the same NUMA node split that node's cores evenly; without topology the available cores are
+    split evenly.  Never returns an empty set (falls back to everything available)."""
+    avail = sorted(available)
+    if local_world <= 1 or not avail:
+        return set(avail)
+    pool, idx, n = avail, local_rank, local_world
+    if gpu_cpulists and local_rank < len(gpu_cpulists) and gpu_cpulists[local_rank]:
+        near = sorted(set(gpu_cpulists[local_rank]) & set(avail))
+        peers = [r for r in range(min(local_world, len(gpu_cpulists))) if gpu_cpulists[r] == gpu_cpulists[local_rank]]
+        if near and len(near) >= len(peers):
+            pool, idx, n = near, peers.index(local_rank), len(peers)
+    per = len(pool) // n
+    if per < 1:
+        return set(avail)
+    return set(pool[idx * per:(idx + 1) * per])
+
+
+def gpu_identity(index):
+    """Where THIS rank's GPU sits: PCI bus id, the cores next to it, its XGMI hive (KFD topology).  Every field is best effort
+    (None when the box does not expose it): the N-GPU line records it so that a slow rank can be named by slot, not by number."""
+    info = {"hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"), "rocr_visible_devices": os.environ.get("ROCR_VISIBLE_DEVICES"),
+            "pci_bus_id": None, "numa_node": None, "local_cpulist": None, "xgmi_hive_id": None}
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        info["pci_bus_id"] = bdf
+        base = "/sys/bus/pci/devices/" + bdf
+        if os.path.exists(base + "/numa_node"):
+            info["numa_node"] = int(open(base + "/numa_node").read())
+        if os.path.exists(base + "/local_cpulist"):
+            info["local_cpulist"] = open(base + "/local_cpulist").read().strip()
+        loc = (pr.pci_bus_id << 8) | (pr.pci_device_id << 3)
+        topo = "/sys/class/kfd/kfd/topology/nodes"
+        for node in sorted(os.listdir(topo)) if os.path.isdir(topo) else []:
+            try:
+                props = dict(ln.split(None, 1) for ln in open(os.path.join(topo, node, "properties")).read().splitlines() if " " in ln)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0 and int(props.get("location_id", "-1")) == loc and int(props.get("domain", "0")) == pr.pci_domain_id:
+                info["xgmi_hive_id"] = props.get("hive_id", "").strip() or None
+                break
+    except Exception as exc:
+        info["error"] = repr(exc)
+    return info
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """sched_setaffinity for this rank (N > 1 only); returns the core list it now runs on, or None when nothing was changed."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("FN2_BENCH_NO_PIN") == "1":
+        return None
+    try:
+        lists = []
+        for d in range(min(local_world, torch.cuda.device_count())):
+            cl = gpu_identity(d).get("local_cpulist")
+            lists.append(frozenset(_parse_cpulist(cl)) if cl else None)
+        cores = rank_cpu_cores(local_rank, local_world, os.sched_getaffinity(0), lists)
+        os.sched_setaffinity(0, cores)
+        torch.set_num_threads(max(1, min(len(cores), 8)))
+        return sorted(cores)
+    except Exception:
+        return None
 
 
 def launch_plan(gpus, device_count, share):
@@ -526,7 +612,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay a hipGraph of the step instead of launching it eagerly")
+    ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=("auto", "on", "off"),
+                    help="replay a hipGraph of the step instead of launching it eagerly; auto = eager at one GPU (the documented "
+                         "headline), graph replay for --gpus N > 1: one launch per step, so that a noisy host core cannot make a "
+                         "rank the slowest of a max-over-ranks timing")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-fast-seconds", type=float, default=12.0)
     ap.add_argument("--model", choices=("auto", "on", "off"), default="auto",
@@ -555,6 +644,8 @@ def main():
     torch.cuda.set_device(local_rank)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pinned = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), local_world)   # before any worker thread exists
 
     hp = HotPath(dev, seed=1234 + rank)   # every rank its own batch: no cross-GPU dependence
     # set-up, before the W warm-up steps: code objects loaded, allocator settled, clocks up (a cold MI355X runs the first
@@ -578,7 +669,7 @@ def main():
     # step, so the other kernels are timed in a second pass.  --graph replays a hipGraph of the step instead (no faster
     # than eager launches once the device is warm: 0.305 ms either way; its roofline then comes from the second pass).
     graph = None
-    if args.graph:
+    if args.graph == "on" or (args.graph == "auto" and world > 1):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -634,6 +725,16 @@ def main():
                  "image_pairs_per_s": round(CORR["B"] * args.steps / float(t[0].item()), 1),
                  "corr_fwd_us_warm": round(float(t[3].item()), 1), "copy_GBps_torch": round(float(t[4].item()), 1),
                  "finite": bool(torch.isfinite(t[1]).item())} for r, t in enumerate(allr)]
+    # where each rank ran: the GPU's slot (PCI bus id, NUMA node, XGMI hive) and the host cores the rank pinned itself to
+    ident = dict(gpu_identity(torch.cuda.current_device()), cpu_cores=(f"{pinned[0]}-{pinned[-1]} ({len(pinned)})" if pinned else None),
+                 host=os.uname().nodename, pid=os.getpid())
+    if dist is not None:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    else:
+        idents = [ident]
+    for pr_, id_ in zip(per_rank, idents):
+        pr_.update(id_)
     # how far the slowest rank is behind the fastest: `value` = N x pairs / slowest rank's time, so this is the run's scaling
     # efficiency relative to N copies of its own fastest rank (the driver computes efficiency across runs from `value` itself)
     rank_balance = round(min(float(t[0].item()) for t in allr) / max(float(t[0].item()) for t in allr), 4)

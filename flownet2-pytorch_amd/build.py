@@ -21,8 +21,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 KERNEL_SRCS = ["capi.hip", "channelnorm.hip", "resample2d.hip", "correlation_direct.hip", "correlation_mfma.hip", "correlation_f16x2.hip", "correlation_f16x2_wide.hip", "correlation_f16_fwd.hip", "correlation_f16_bwd.hip", "correlation_f16x2_bwd.hip", "correlation_fused_bwd.hip", "correlation_f16x2_bwd_wide.hip", "correlation_mfma_bwd.hip",
                "multiscale_loss.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-             "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
-MODULES = ["correlation_cuda", "resample2d_cuda", "channelnorm_cuda"]
+             "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+MODULES = ["correlation_cuda", "resample2d_cuda", "channelnorm_cuda", "multiscale_loss_cuda"]
 
 
 def _newer(target, deps):
@@ -59,8 +59,8 @@ def build_lib(force=False, debug=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(_run, jobs))
-    if force or not _newer(lib, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    if force or not _newer(lib, objs + [os.path.join(CSRC, "exports.map")]):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", lib] + objs)
     return lib
 
 

@@ -72,8 +72,39 @@ at::Tensor channelnorm_backward_alloc(at::Tensor &input1, at::Tensor &output, at
     return g;
 }
 
+// ---- autograd Function on the C++ side; semantics of networks/channelnorm_package/channelnorm.py
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+struct ChannelNormOp : public torch::autograd::Function<ChannelNormOp> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &input1, int64_t norm_deg)
+    {
+        TORCH_CHECK(input1.is_contiguous(), "ChannelNormFunction: input1 must be contiguous (reference channelnorm.py:9)");
+        at::Tensor a = input1;
+        at::Tensor output = channelnorm_forward_alloc(a, (int)norm_deg);
+        ctx->save_for_backward({input1, output});
+        ctx->saved_data["n"] = norm_deg;
+        return output;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_outputs)
+    {
+        TORCH_CHECK(!(grad_outputs[0].requires_grad() && at::GradMode::is_enabled()),
+                    "ChannelNormFunction.backward: a HIP kernel, not differentiable a second time (create_graph=True)");
+        auto saved = ctx->get_saved_variables();
+        at::Tensor a = saved[0], o = saved[1], go = grad_outputs[0];
+        return {channelnorm_backward_alloc(a, o, go, (int)ctx->saved_data["n"].toInt()), at::Tensor()};
+    }
+};
+
+at::Tensor channelnorm_apply(const at::Tensor &input1, int64_t norm_deg)
+{
+    return ChannelNormOp::apply(input1, norm_deg);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("apply", &channelnorm_apply, "ChannelNormFunction.apply: differentiable, autograd node on the C++ side", py::arg("input1"), py::arg("norm_deg") = 2);
     m.def("forward_alloc", &channelnorm_forward_alloc, "forward returning a freshly allocated output");
     m.def("backward_alloc", &channelnorm_backward_alloc, "backward returning a freshly allocated gradient");
     m.doc() = "FlowNet2 ChannelNorm layer, gfx950 HIP kernels (drop-in for the reference channelnorm_cuda)";

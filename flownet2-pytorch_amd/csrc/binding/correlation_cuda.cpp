@@ -69,12 +69,18 @@ int correlation_forward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::Te
 // correlation_cuda_kernel.cu:229): widen, run, narrow -- three elementwise passes around a 0.3 ms kernel instead of 9 ms.
 // Shared by backward and backward_fused.  `go`: the contiguous half gradient.  false = not this corner (or a shape the
 // fp32 launchers decline): the caller's half path takes it.
+// The shapes that corner covers (pure predicate: callers test it BEFORE preparing operands for it).
+static bool half_wide_applies(int dt, int C, int H, int W, int pad_size, int kernel_size, int max_displacement, int stride1, int stride2)
+{
+    return dt == FN2_F16 && W > 64 && kernel_size == 1 && stride1 == 1 && stride2 == 2 && pad_size == max_displacement &&
+           max_displacement == 20 && C % 64 == 0 && H % 2 == 0 && W % 8 == 0;
+}
+
 static bool half_wide_backward(const at::Tensor &a, const at::Tensor &b, const at::Tensor &go, at::Tensor &gradInput1, at::Tensor &gradInput2,
                                int dt, int B, int C, int H, int W, int pad_size, int kernel_size, int max_displacement, int stride1,
                                int stride2)
 {
-    if (!(dt == FN2_F16 && W > 64 && kernel_size == 1 && stride1 == 1 && stride2 == 2 && pad_size == max_displacement &&
-          max_displacement == 20 && C % 64 == 0 && H % 2 == 0 && W % 8 == 0))
+    if (!half_wide_applies(dt, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2))
         return false;
     at::Tensor a32 = a.to(at::kFloat), b32 = b.to(at::kFloat), go32 = go.to(at::kFloat);
     at::Tensor g1 = at::empty_like(a32), g2 = at::empty_like(b32);
@@ -152,7 +158,10 @@ int correlation_backward_fused_hip(at::Tensor &input1, at::Tensor &input2, at::T
     gradInput1.resize_({B, C, H, W});
     gradInput2.resize_({B, C, H, W});
     TORCH_CHECK(gradInput1.is_contiguous() && gradInput2.is_contiguous(), op, ": gradInputs must be contiguous");
-    if (dt == FN2_F16 && W > 64) {
+    // the activation's derivative is read off the SIGN of the stored output: only an increasing activation keeps it
+    // (fn2_correlation_backward_fused enforces the same; checked here so that no branch below can run without it)
+    TORCH_CHECK(negative_slope > 0, op, ": negative_slope must be > 0, got ", negative_slope);
+    if (half_wide_applies(dt, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)) {
         // the masked gradient as autograd's leaky_relu_backward forms it for half tensors (fp32 product, rounded to half once), then
         // the same widened path as `backward`: fused and unfused training give the same gradients on Sintel-size maps too
         at::Tensor outs = buffer.narrow(1, channel_offset, nOut), gs = gb.narrow(1, channel_offset, nOut).to(at::kFloat);
@@ -194,8 +203,99 @@ std::vector<at::Tensor> correlation_backward_alloc(at::Tensor &input1, at::Tenso
     return {g1, g2};
 }
 
+// ---- autograd Functions on the C++ side: `Correlation` / `CorrelationLeakyReLUCat` do no Python between
+// `apply` and the launch, and the engine calls the backward without taking the GIL.  Same semantics as the Python Functions of
+// networks/correlation_package/correlation.py (kept there for code written against CorrelationFunction.forward / .backward).
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+static void check_once_differentiable(const variable_list &grads, const char *op)
+{
+    for (const auto &g : grads)
+        TORCH_CHECK(!(g.defined() && g.requires_grad() && at::GradMode::is_enabled()), op,
+                    ": the backward of this layer is a HIP kernel and not differentiable a second time (create_graph=True)");
+}
+
+struct CorrelationOp : public torch::autograd::Function<CorrelationOp> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &input1, const at::Tensor &input2, int64_t pad_size, int64_t kernel_size,
+                              int64_t max_displacement, int64_t stride1, int64_t stride2, int64_t corr_multiply)
+    {
+        ctx->save_for_backward({input1, input2});
+        ctx->saved_data["p"] = std::vector<int64_t>{pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply};
+        at::Tensor a = input1, b = input2;
+        return correlation_forward_alloc(a, b, (int)pad_size, (int)kernel_size, (int)max_displacement, (int)stride1, (int)stride2, (int)corr_multiply);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_outputs)
+    {
+        check_once_differentiable(grad_outputs, "CorrelationFunction.backward");
+        auto saved = ctx->get_saved_variables();
+        const auto p = ctx->saved_data["p"].toIntVector();
+        at::Tensor a = saved[0], b = saved[1], go = grad_outputs[0];
+        auto g = correlation_backward_alloc(a, b, go, (int)p[0], (int)p[1], (int)p[2], (int)p[3], (int)p[4], (int)p[5]);
+        return {g[0], g[1], at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor correlation_apply(const at::Tensor &input1, const at::Tensor &input2, int64_t pad_size, int64_t kernel_size, int64_t max_displacement,
+                             int64_t stride1, int64_t stride2, int64_t corr_multiply)
+{
+    return CorrelationOp::apply(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply);
+}
+
+// cat((redir, leaky_relu(corr(input1, input2), slope)), 1) (FlowNetC.py:86-87, :92) as one differentiable op
+struct CorrelationLeakyReLUCatOp : public torch::autograd::Function<CorrelationLeakyReLUCatOp> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &input1, const at::Tensor &input2, const at::Tensor &redir, int64_t pad_size,
+                              int64_t kernel_size, int64_t max_displacement, int64_t stride1, int64_t stride2, double negative_slope)
+    {
+        const char *op = "CorrelationLeakyReLUCat";
+        check_gpu(input1, op, "input1");
+        check_same(input1, redir, op, "redir");
+        TORCH_CHECK(redir.dim() == 4, op, ": redir must be 4-D");
+        TORCH_CHECK(stride2 > 0, op, ": stride2 must be positive");
+        const int64_t r = max_displacement / stride2, n_out = (2 * r + 1) * (2 * r + 1), Cr = redir.size(1);
+        c10::DeviceGuard guard(input1.device());
+        at::Tensor buf = at::empty({redir.size(0), Cr + n_out, redir.size(2), redir.size(3)}, redir.options());
+        buf.narrow(1, 0, Cr).copy_(redir);
+        at::Tensor a = input1, b = input2;
+        correlation_forward_fused_hip(a, b, buf, (int)Cr, negative_slope, (int)pad_size, (int)kernel_size, (int)max_displacement, (int)stride1, (int)stride2);
+        ctx->save_for_backward({input1, input2, buf});
+        ctx->saved_data["p"] = std::vector<int64_t>{pad_size, kernel_size, max_displacement, stride1, stride2, Cr};
+        ctx->saved_data["slope"] = negative_slope;
+        return buf;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_outputs)
+    {
+        check_once_differentiable(grad_outputs, "CorrelationLeakyReLUCatFunction.backward");
+        auto saved = ctx->get_saved_variables();
+        const auto p = ctx->saved_data["p"].toIntVector();
+        const double slope = ctx->saved_data["slope"].toDouble();
+        at::Tensor a = saved[0], b = saved[1], buf = saved[2], gbuf = grad_outputs[0];
+        at::Tensor g1, g2, gr;
+        if (ctx->needs_input_grad(0) || ctx->needs_input_grad(1)) {
+            c10::DeviceGuard guard(a.device());
+            g1 = at::empty({0}, a.options());
+            g2 = at::empty({0}, a.options());
+            correlation_backward_fused_hip(a, b, buf, gbuf, (int)p[5], slope, g1, g2, (int)p[0], (int)p[1], (int)p[2], (int)p[3], (int)p[4]);
+        }
+        if (ctx->needs_input_grad(2)) gr = gbuf.narrow(1, 0, p[5]);
+        return {g1, g2, gr, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor correlation_leakyrelu_cat_apply(const at::Tensor &input1, const at::Tensor &input2, const at::Tensor &redir, int64_t pad_size,
+                                           int64_t kernel_size, int64_t max_displacement, int64_t stride1, int64_t stride2, double negative_slope)
+{
+    return CorrelationLeakyReLUCatOp::apply(input1, input2, redir, pad_size, kernel_size, max_displacement, stride1, stride2, negative_slope);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("apply", &correlation_apply, "CorrelationFunction.apply: differentiable, autograd node on the C++ side", py::arg("input1"), py::arg("input2"),
+          py::arg("pad_size") = 3, py::arg("kernel_size") = 3, py::arg("max_displacement") = 20, py::arg("stride1") = 1, py::arg("stride2") = 2,
+          py::arg("corr_multiply") = 1);
+    m.def("leakyrelu_cat_apply", &correlation_leakyrelu_cat_apply, "CorrelationLeakyReLUCatFunction.apply: differentiable, autograd node on the C++ side");
     m.def("forward_alloc", &correlation_forward_alloc, "forward returning a freshly allocated output");
     m.def("backward_alloc", &correlation_backward_alloc, "backward returning freshly allocated gradients");
     m.doc() = "FlowNet2 correlation layer, gfx950 HIP kernels (drop-in for the reference correlation_cuda)";

@@ -194,8 +194,120 @@ std::vector<at::Tensor> resample2d_backward_alloc(at::Tensor &input1, at::Tensor
     return {g1, g2};
 }
 
+// ---- autograd Functions on the C++ side: no Python between `apply` and the launch, no GIL in the backward.
+// Same semantics as the Python Functions of networks/resample2d_package/resample2d.py.
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+static void check_once_differentiable(const variable_list &grads, const char *op)
+{
+    for (const auto &g : grads)
+        TORCH_CHECK(!(g.defined() && g.requires_grad() && at::GradMode::is_enabled()), op,
+                    ": the backward of this layer is a HIP kernel and not differentiable a second time (create_graph=True)");
+}
+
+struct Resample2dOp : public torch::autograd::Function<Resample2dOp> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &input1, const at::Tensor &input2, int64_t kernel_size, bool bilinear)
+    {
+        TORCH_CHECK(input2.is_contiguous(), "Resample2dFunction: flow must be contiguous (reference resample2d.py:10)");
+        ctx->save_for_backward({input1, input2});
+        ctx->saved_data["k"] = kernel_size;
+        ctx->saved_data["b"] = bilinear;
+        at::Tensor a = input1, f = input2;
+        return resample2d_forward_alloc(a, f, (int)kernel_size, bilinear);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_outputs)
+    {
+        check_once_differentiable(grad_outputs, "Resample2dFunction.backward");
+        auto saved = ctx->get_saved_variables();
+        at::Tensor a = saved[0], f = saved[1], go = grad_outputs[0];
+        auto g = resample2d_backward_alloc(a, f, go, (int)ctx->saved_data["k"].toInt(), ctx->saved_data["b"].toBool());
+        return {g[0], g[1], at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor resample2d_apply(const at::Tensor &input1, const at::Tensor &input2, int64_t kernel_size, bool bilinear)
+{
+    return Resample2dOp::apply(input1, input2, kernel_size, bilinear);
+}
+
+// models.py:133-138 as one differentiable op (fn2_warp_diff_norm_cat / fn2_warp_diff_norm_cat_backward)
+struct WarpDiffNormCatOp : public torch::autograd::Function<WarpDiffNormCatOp> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &x_, const at::Tensor &flow_, double div_flow, bool bilinear)
+    {
+        const char *op = "WarpDiffNormCat";
+        check_gpu(x_, op, "x");
+        check_same(x_, flow_, op, "flow");
+        TORCH_CHECK(x_.dim() == 4 && x_.size(1) % 2 == 0 && x_.size(1) > 0, op, ": x must be 4-D with two images, got ", x_.sizes());
+        c10::DeviceGuard guard(x_.device());
+        at::Tensor x = x_.contiguous(), flow = flow_.contiguous();
+        const int64_t c2 = x.size(1);
+        at::Tensor out = at::empty({x.size(0), c2 + c2 / 2 + 3, x.size(2), x.size(3)}, x.options());
+        warp_diff_norm_cat_hip(x, flow, out, div_flow, bilinear);
+        ctx->save_for_backward({x, flow, out});
+        ctx->saved_data["d"] = div_flow;
+        ctx->saved_data["b"] = bilinear;
+        return out;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_outputs)
+    {
+        check_once_differentiable(grad_outputs, "WarpDiffNormCatFunction.backward");
+        const bool need_x = ctx->needs_input_grad(0), need_flow = ctx->needs_input_grad(1);
+        if (!(need_x || need_flow)) return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        auto saved = ctx->get_saved_variables();
+        at::Tensor x = saved[0], flow = saved[1], out = saved[2];
+        c10::DeviceGuard guard(x.device());
+        at::Tensor go = grad_outputs[0].contiguous();
+        at::Tensor gx = need_x ? at::empty_like(x) : at::empty({0}, x.options());
+        at::Tensor gflow = at::empty_like(flow);
+        warp_diff_norm_cat_backward_hip(x, flow, out, go, gx, gflow, ctx->saved_data["d"].toDouble(), ctx->saved_data["b"].toBool());
+        return {need_x ? gx : at::Tensor(), need_flow ? gflow : at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor warp_diff_norm_cat_apply(const at::Tensor &x, const at::Tensor &flow, double div_flow, bool bilinear)
+{
+    return WarpDiffNormCatOp::apply(x, flow, div_flow, bilinear);
+}
+
+// models.py:157-161 / :170-174 as one differentiable op (flow gradient only; the caller composes the unfused layers when the pair
+// itself needs a gradient)
+struct WarpDiffNormOp : public torch::autograd::Function<WarpDiffNormOp> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &x_, const at::Tensor &flow_, bool bilinear)
+    {
+        check_gpu(x_, "WarpDiffNorm", "x");
+        c10::DeviceGuard guard(x_.device());
+        at::Tensor x = x_.contiguous(), flow = flow_.contiguous();
+        at::Tensor norm = warp_diff_norm_hip(x, flow, bilinear);
+        ctx->save_for_backward({x, flow, norm});
+        ctx->saved_data["b"] = bilinear;
+        return norm;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_outputs)
+    {
+        check_once_differentiable(grad_outputs, "WarpDiffNormFunction.backward");
+        if (!ctx->needs_input_grad(1)) return {at::Tensor(), at::Tensor(), at::Tensor()};
+        auto saved = ctx->get_saved_variables();
+        at::Tensor x = saved[0], flow = saved[1], norm = saved[2];
+        at::Tensor gn = grad_outputs[0];
+        return {at::Tensor(), warp_diff_norm_backward_hip(x, flow, norm, gn, ctx->saved_data["b"].toBool()), at::Tensor()};
+    }
+};
+
+at::Tensor warp_diff_norm_apply(const at::Tensor &x, const at::Tensor &flow, bool bilinear)
+{
+    return WarpDiffNormOp::apply(x, flow, bilinear);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("apply", &resample2d_apply, "Resample2dFunction.apply: differentiable, autograd node on the C++ side", py::arg("input1"), py::arg("input2"),
+          py::arg("kernel_size") = 1, py::arg("bilinear") = true);
+    m.def("warp_diff_norm_cat_apply", &warp_diff_norm_cat_apply, "WarpDiffNormCatFunction.apply: differentiable, autograd node on the C++ side");
+    m.def("warp_diff_norm_apply", &warp_diff_norm_apply, "WarpDiffNormFunction.apply: differentiable, autograd node on the C++ side");
     m.def("forward_alloc", &resample2d_forward_alloc, "forward returning a freshly allocated output");
     m.def("backward_alloc", &resample2d_backward_alloc, "backward returning freshly allocated gradients");
     m.doc() = "FlowNet2 Resample2d layer, gfx950 HIP kernels (drop-in for the reference resample2d_cuda)";

@@ -13,6 +13,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the libraries are built with -fvisibility=hidden */
 int fn2_debug_correlation_forward(const void *in1, const void *in2, void *out, int dtype, int B, int C, int H, int W,
                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
                                   int variant, void *stream);
@@ -36,6 +37,7 @@ int fn2_debug_stream_copy(void *dst, const void *src, size_t bytes, int blocks, 
 int fn2_debug_mfma_probe(void *sink, int iters, int workgroups, double *flop, void *stream);
 /* out[b] = HW_REG_XCC_ID of workgroup b of a 1-D grid of `workgroups` (device array of ints) */
 int fn2_debug_xcc_census(int *out, int workgroups, void *stream);
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

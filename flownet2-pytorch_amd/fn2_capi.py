@@ -22,6 +22,7 @@ EXPORTS = [
     "fn2_warp_diff_norm_cat_backward", "fn2_warp_diff_norm", "fn2_warp_diff_norm_backward",
     "fn2_channelnorm_forward", "fn2_channelnorm_backward",
     "fn2_multiscale_workspace_bytes", "fn2_multiscale_l1_epe", "fn2_multiscale_loss",
+    "fn2_multiscale_loss_fused", "fn2_multiscale_scale_grads",
 ]
 
 # profiling / ablation entry points (csrc/fn2_debug.h): not in include/flownet2_hip.h, results wrong by design; exported by

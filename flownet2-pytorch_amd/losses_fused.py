@@ -14,6 +14,7 @@ from torch import nn
 from torch.autograd import Function
 
 import fn2_capi
+import multiscale_loss_cuda  # built by flownet2-pytorch_amd/build.py (csrc/binding/multiscale_loss_cuda.cpp); no fallback on purpose
 
 
 def EPE(input_flow, target_flow):
@@ -22,6 +23,11 @@ def EPE(input_flow, target_flow):
 
 
 class MultiScaleFunction(Function):
+    """The node in Python over the ctypes view of the C ABI (rounds 3-5).  Since round 6 GPU tensors take the C++ node
+    ``multiscale_loss_cuda.apply`` instead (one launch forward -- loss and metric written by the kernel --, one launch backward, no
+    host arrays marshalled per call); this class remains for callers of its static methods and as the specification the CPU pin test
+    drives with the kernel call replaced (tests/test_losses_pin.py)."""
+
     @staticmethod
     def forward(ctx, target, start_scale, div_flow, weights, coef, norm, *outputs):
         # which predictions want a gradient: asked of autograd, not of the (no-grad) contiguous copies made below
@@ -61,6 +67,9 @@ class MultiScale(nn.Module):
             epe = EPE(output, target)
             return [torch.abs(output - target).mean() if self._norm == 1 else torch.norm(output - target, p=2, dim=1).mean(), epe]
         assert isinstance(output, (tuple, list)) and len(output) == self.numScales
+        if target.is_cuda:
+            loss, epe = multiscale_loss_cuda.apply(target, list(output), self.startScale, self.div_flow, self.loss_weights, self._norm)
+            return [loss, epe]
         key = (target.device, tuple(o.numel() for o in output))
         coef = self._coef.get(key)
         if coef is None:

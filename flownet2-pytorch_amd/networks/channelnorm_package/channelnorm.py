@@ -10,11 +10,18 @@ reference reads the non-contiguous slice autograd hands it as if it were contigu
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 import channelnorm_cuda  # built by flownet2-pytorch_amd/build.py; no fallback on purpose
 
 
 class ChannelNormFunction(Function):
+    """``apply`` = the C++ autograd node ``channelnorm_cuda.apply``; ``forward`` / ``backward`` are the same two calls in Python."""
+
+    @classmethod
+    def apply(cls, input1, norm_deg=2):
+        assert input1.is_contiguous(), "input1 must be contiguous (reference channelnorm.py:9)"
+        return channelnorm_cuda.apply(input1, norm_deg)
 
     @staticmethod
     def forward(ctx, input1, norm_deg=2):
@@ -25,6 +32,7 @@ class ChannelNormFunction(Function):
         return output
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
         input1, output = ctx.saved_tensors
         return channelnorm_cuda.backward_alloc(input1, output, grad_output, ctx.norm_deg), None

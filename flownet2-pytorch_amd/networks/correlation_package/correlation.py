@@ -10,13 +10,22 @@ module fails loudly if it has not been built.
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 import correlation_cuda  # built by flownet2-pytorch_amd/build.py; no fallback on purpose
 
 
 class CorrelationFunction(Function):
     """out[n, tj*D+ti, y, x] = mean_c in1[n,c,y',x'] * in2[n,c,y'+tj*s2,x'+ti*s2] (reference
-    correlation_cuda_kernel.cu:73-147); backward per :150-334."""
+    correlation_cuda_kernel.cu:73-147); backward per :150-334.
+
+    ``apply`` goes straight to the autograd node the extension implements in C++ (``correlation_cuda.apply``: no Python between
+    ``apply`` and the launch, no GIL in the backward); ``forward`` / ``backward`` below are the same two calls for code written
+    against the reference's static methods."""
+
+    @classmethod
+    def apply(cls, input1, input2, pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2, corr_multiply=1):
+        return correlation_cuda.apply(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
 
     @staticmethod
     def forward(ctx, input1, input2, pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2,
@@ -28,6 +37,7 @@ class CorrelationFunction(Function):
         return correlation_cuda.forward_alloc(input1, input2, *ctx.corr_params)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
         input1, input2 = ctx.saved_tensors
         grad_input1, grad_input2 = correlation_cuda.backward_alloc(input1, input2, grad_output, *ctx.corr_params)
@@ -57,7 +67,15 @@ class CorrelationLeakyReLUCatFunction(Function):
     """``cat((redir, leaky_relu(corr(input1, input2), slope)), 1)`` (FlowNetC.py:86-87, :92) as one differentiable op: forward =
     the correlation kernel with the activation and the store into the concat buffer fused into its epilogue; backward = the
     gradient of the buffer's correlation slice read in place, the activation's derivative taken from the sign of the stored
-    output (no mask, no saved pre-activation), the correlation backward kernels (correlation_cuda.backward_fused)."""
+    output (no mask, no saved pre-activation), the correlation backward kernels (correlation_cuda.backward_fused).
+    ``apply`` = the C++ autograd node ``correlation_cuda.leakyrelu_cat_apply``; the static methods are the same calls in Python."""
+
+    @classmethod
+    def apply(cls, input1, input2, redir, pad_size, kernel_size, max_displacement, stride1, stride2, negative_slope):
+        if not negative_slope > 0 and (input1.requires_grad or input2.requires_grad):
+            raise ValueError("CorrelationLeakyReLUCatFunction differentiates only for negative_slope > 0")
+        return correlation_cuda.leakyrelu_cat_apply(input1, input2, redir, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                                    float(negative_slope))
 
     @staticmethod
     def forward(ctx, input1, input2, redir, pad_size, kernel_size, max_displacement, stride1, stride2, negative_slope):
@@ -76,6 +94,7 @@ class CorrelationLeakyReLUCatFunction(Function):
         return buf
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_buf):
         input1, input2, buf = ctx.saved_tensors
         Cr = ctx.channel_offset

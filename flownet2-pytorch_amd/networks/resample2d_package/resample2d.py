@@ -11,11 +11,21 @@ passes in.
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 import resample2d_cuda  # built by flownet2-pytorch_amd/build.py; no fallback on purpose
 
 
 class Resample2dFunction(Function):
+    """``apply`` = the C++ autograd node ``resample2d_cuda.apply`` (no Python between ``apply`` and the launch, no GIL in the backward);
+    ``forward`` / ``backward`` are the same two calls in Python for code written against the reference's static methods."""
+
+    @classmethod
+    def apply(cls, input1, input2, kernel_size=1, bilinear=True):
+        assert input2.is_contiguous(), "flow must be contiguous (reference resample2d.py:10)"
+        if int(kernel_size) < 1:
+            raise ValueError("Resample2d: kernel_size must be >= 1")
+        return resample2d_cuda.apply(input1, input2, int(kernel_size), bool(bilinear))
 
     @staticmethod
     def forward(ctx, input1, input2, kernel_size=1, bilinear=True):
@@ -28,6 +38,7 @@ class Resample2dFunction(Function):
         return resample2d_cuda.forward_alloc(input1, input2, kernel_size, bilinear)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
         input1, input2 = ctx.saved_tensors
         # grad_input1 is accumulated into by the kernel (fp32 atomics), so it starts at zero (reference resample2d.py:31): zeros and the
@@ -54,7 +65,12 @@ class Resample2d(nn.Module):
 class WarpDiffNormCatFunction(Function):
     """models.py:133-138 as one differentiable op: forward = fn2_warp_diff_norm_cat, backward = fn2_warp_diff_norm_cat_backward
     (the gradient through resample -> difference -> ChannelNorm -> cat in one kernel; no scatter at all when the image pair
-    needs no gradient, which is the case in FlowNet2, where it is the network's input)."""
+    needs no gradient, which is the case in FlowNet2, where it is the network's input).  ``apply`` = the C++ autograd node
+    ``resample2d_cuda.warp_diff_norm_cat_apply``."""
+
+    @classmethod
+    def apply(cls, x, flow, div_flow, bilinear):
+        return resample2d_cuda.warp_diff_norm_cat_apply(x, flow, float(div_flow), bool(bilinear))
 
     @staticmethod
     def forward(ctx, x, flow, div_flow, bilinear):
@@ -67,6 +83,7 @@ class WarpDiffNormCatFunction(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         x, flow, out = ctx.saved_tensors
         need_x, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -100,7 +117,12 @@ class WarpDiffNormCat(nn.Module):
 class WarpDiffNormFunction(Function):
     """models.py:157-161 / :170-174 as one differentiable op: ``ChannelNorm(x[:, :3] - Resample2d(x[:, 3:], flow))``.  Forward = the fused
     kernel storing only the norm plane; backward w.r.t. the flow = one gather-only kernel that recomputes the warp
-    (fn2_warp_diff_norm_backward).  When the image pair itself needs a gradient the unfused layers are composed under autograd."""
+    (fn2_warp_diff_norm_backward).  When the image pair itself needs a gradient the unfused layers are composed under autograd.
+    ``apply`` = the C++ autograd node ``resample2d_cuda.warp_diff_norm_apply``."""
+
+    @classmethod
+    def apply(cls, x, flow, bilinear):
+        return resample2d_cuda.warp_diff_norm_apply(x, flow, bool(bilinear))
 
     @staticmethod
     def forward(ctx, x, flow, bilinear):
@@ -111,6 +133,7 @@ class WarpDiffNormFunction(Function):
         return norm
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_norm):
         x, flow, norm = ctx.saved_tensors
         grad_flow = resample2d_cuda.warp_diff_norm_backward(x, flow, norm, grad_norm.contiguous(), ctx.bilinear) if ctx.needs_input_grad[1] else None
@@ -130,5 +153,7 @@ class WarpDiffNorm(nn.Module):
             # the pair itself wants a gradient (not the case in FlowNet2, where it is the input): the unfused layers under autograd
             from networks.channelnorm_package.channelnorm import ChannelNormFunction
             c = x.shape[1] // 2
-            return ChannelNormFunction.apply(x[:, :c] - Resample2dFunction.apply(x[:, c:], flow, 1, self.bilinear), 2)
+            # (flow made contiguous like the fused path does: the same module must not accept a strided flow or raise depending on
+            # whether the pair wants a gradient -- ADVICE r5)
+            return ChannelNormFunction.apply(x[:, :c] - Resample2dFunction.apply(x[:, c:], flow.contiguous(), 1, self.bilinear), 2)
         return WarpDiffNormFunction.apply(x, flow, self.bilinear)

@@ -34,11 +34,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports, literally */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* 2 (round 5): + fn2_multiscale_loss, fn2_warp_diff_norm_cat_backward, fn2_warp_diff_norm,
  * fn2_warp_diff_norm_backward.  Additive: every version-1 entry point keeps its
  * signature and meaning; a caller built against version 1 runs unchanged on a version-2 library. */
-#define FN2_ABI_VERSION 2
+/* 3 (round 6): + fn2_multiscale_loss_fused, fn2_multiscale_scale_grads; fn2_multiscale_workspace_bytes grew by the ticket counter's
+ * 64-byte line (callers size their scratch with it, as before).  Additive as well. */
+#define FN2_ABI_VERSION 3
 
 /* element types (reference dispatch: AT_DISPATCH_FLOATING_TYPES_AND_HALF for correlation and
  * channelnorm -- correlation_cuda_kernel.cu:386-415, channelnorm_kernel.cu:111,152; float only
@@ -247,8 +253,8 @@ int fn2_warp_diff_norm_backward(const float *pair, const float *flow, const floa
  *   grads      : NULL, or num_scales device tensors shaped like outputs[i], fully written with
  *                grad_scale * weights[i] / (B*2*H_i*W_i) * sign(out_i - t_i) = d(sum_i w_i L1_i)/d out_i * grad_scale
  *   weights    : host array of num_scales loss weights (only used for grads)
- *   workspace  : device scratch of fn2_multiscale_workspace_bytes(...) bytes (per-workgroup partial sums; the result is
- *                deterministic)
+ *   workspace  : device scratch of fn2_multiscale_workspace_bytes(...) bytes (per-workgroup partial sums and a ticket counter:
+ *                the last workgroup to finish adds the partial sums in a fixed order -- the result is deterministic)
  * float32. */
 size_t fn2_multiscale_workspace_bytes(int B, int H, int W, int start_scale, int num_scales);
 int fn2_multiscale_l1_epe(const float *const *outputs, const float *target, float *sums, float *const *grads,
@@ -261,6 +267,24 @@ int fn2_multiscale_l1_epe(const float *const *outputs, const float *target, floa
 int fn2_multiscale_loss(const float *const *outputs, const float *target, float *sums, float *const *grads,
                         const float *weights, float grad_scale, int norm, int B, int H, int W, int start_scale, int num_scales,
                         float div_flow, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Row N3 as the autograd node uses it (ABI v3): the same pass, with the weighted means themselves written by the kernel --
+ *   loss_epe[0] = sum_i weights[i] * L_i   (norm 1: L_i = sums[i] / (B*2*H_i*W_i); norm 2: L_i = sums[n+i] / (B*H_i*W_i), losses.py:21-26)
+ *   loss_epe[1] = sum_i weights[i] * sums[n+i] / (B*H_i*W_i)                                               (losses.py:77)
+ * -- by the last workgroup to finish (a ticket counter at the end of `workspace`; the summation order is fixed, the result
+ * deterministic), so that loss and metric cost ONE launch.  workspace_primed != 0: the caller guarantees that the workspace was
+ * zero-filled once and has since only been used by this entry point on one stream at a time (the kernel leaves the counter at
+ * zero); 0: the counter is cleared by a 4-byte memset node in front of the kernel (any scratch memory will do).  `weights` is
+ * required. */
+int fn2_multiscale_loss_fused(const float *const *outputs, const float *target, float *sums, float *loss_epe, float *const *grads,
+                              const float *weights, float grad_scale, int norm, int B, int H, int W, int start_scale, int num_scales,
+                              float div_flow, void *workspace, size_t workspace_bytes, int workspace_primed, void *stream);
+/* grads[i][j] = unit_grads[i][j] * *scale for i < num_scales, j < numel[i], in one launch: the backward of the node above for an
+ * incoming gradient that lives on the device (unit_grads = what fn2_multiscale_loss_fused wrote with grad_scale 1).  `scale`: device
+ * pointer to one float; unit_grads / grads / numel: host arrays.  Out of place, so that a retained graph sees its saved gradients
+ * unchanged. (ABI v3) */
+int fn2_multiscale_scale_grads(const float *const *unit_grads, float *const *grads, const int64_t *numel, int num_scales,
+                               const float *scale, void *stream);
 
 /* Replaces channelnorm_kernel_forward (channelnorm_kernel.cuh:5-8; kernel
  * channelnorm_kernel.cu:18-60).  in : B x C x H x W contiguous, out : B x 1 x H x W contiguous.
@@ -275,6 +299,9 @@ int fn2_channelnorm_forward(const void *in, void *out, int dtype, int B, int C, 
 int fn2_channelnorm_backward(const void *in, const void *out, const void *grad_out, const int64_t *gout_strides,
                              void *grad_in, int dtype, int B, int C, int H, int W, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,52 @@ def test_self_launch_reports_missing_gpus_without_hanging():
         assert r.returncode != 0 and ("GPU" in r.stderr)
 
 
+def test_rank_cpu_cores_are_disjoint_and_cover_the_node():
+    """VERDICT r5 next #7: every rank of an N-GPU run pins itself to its own host cores (near its GPU where the box says which)."""
+    avail = set(range(256))
+    flat = [bench.rank_cpu_cores(r, 8, avail) for r in range(8)]
+    assert all(len(c) == 32 for c in flat) and len(set().union(*flat)) == 256
+    assert all(flat[i].isdisjoint(flat[j]) for i in range(8) for j in range(i))
+    # two NUMA nodes, four GPUs each: a rank's cores come from ITS GPU's node, split four ways
+    near = [frozenset(range(0, 128))] * 4 + [frozenset(range(128, 256))] * 4
+    numa = [bench.rank_cpu_cores(r, 8, avail, near) for r in range(8)]
+    assert all(len(c) == 32 for c in numa) and all(numa[i].isdisjoint(numa[j]) for i in range(8) for j in range(i))
+    assert numa[1] <= set(range(0, 128)) and numa[5] <= set(range(128, 256)) and numa[4] == set(range(128, 160))
+    # a restricted affinity mask (container with 8 cores), more ranks than cores, no topology for some GPUs, one rank: never empty
+    assert bench.rank_cpu_cores(3, 8, set(range(8))) == {3}
+    assert bench.rank_cpu_cores(3, 16, set(range(8))) == set(range(8))
+    assert bench.rank_cpu_cores(1, 2, set(range(8)), [None, None]) == {4, 5, 6, 7}
+    assert bench.rank_cpu_cores(0, 1, {2, 3}) == {2, 3}
+    assert bench.rank_cpu_cores(1, 2, set(range(8)), [frozenset({100}), frozenset({100})]) == {4, 5, 6, 7}   # "near" cores not available
+    assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    info = bench.gpu_identity(0)                                        # no GPU here: every field present, nothing raises
+    assert {"pci_bus_id", "numa_node", "local_cpulist", "xgmi_hive_id", "hip_visible_devices"} <= set(info)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_model_on():
+    """ADVICE r5 (medium): `--gpus N --model on` staggers MIOpen's kernel search (rank 0 first) -- that warm-up must issue no
+    collective, or rank 0's gradient all-reduce meets the other ranks' barrier.  Two ranks (RCCL on a 2-GPU box, else the shared-GPU
+    gloo dry run, where a mismatched collective is a hard error rather than a hang): the whole FlowNet2C pass must complete."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    share = torch.cuda.device_count() < 2
+    if share:
+        env["FN2_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--model", "on", "--model-steps", "2", "--model-warmup", "1", "--model-timeout", "900"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    m = line["flownet2c"]
+    assert "error" not in m, m
+    assert m["train_step_ms"] > 0 and m["fwd_bwd_ms"] > 0 and m["inference_ms"] > 0 and m["grad_buckets"] >= 2
+    assert line["launch"].startswith("hipGraph")                        # N > 1 replays a graph of the step by default
+    assert all("pci_bus_id" in p and "cpu_cores" in p for p in line["per_rank"])
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_self_launch():
     import torch

