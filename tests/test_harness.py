@@ -307,6 +307,92 @@ def test_flownet2_hip_layers_vs_torch_stand_ins(dev):
     assert float((hip - ref).abs().max()) <= 1e-3 * scale, (float((hip - ref).abs().max()), scale)
 
 
+def _capture_fused_rows(modules):
+    """Forward pre/post hooks on the fused-row modules of a network: for every call, the input tensors (detached copies), the output, the
+    gradient that arrives at the output and the gradients the row sends to each differentiable input -- taken on a VIEW of the input
+    made for this call, so that what other consumers of the same tensor contribute (flow_s2 also feeds the fusion network) is not in it."""
+    calls, handles = [], []
+
+    def pre(mod, args):
+        rec = {"mod": mod, "inputs": [a.detach().clone() for a in args], "gin": [None] * len(args)}
+        views = []
+        for k, a in enumerate(args):
+            v = a.view_as(a)
+            if v.requires_grad:
+                v.register_hook(lambda g, rec=rec, k=k: rec["gin"].__setitem__(k, g.detach().clone()))
+            views.append(v)
+        mod._fn2_rec = rec
+        return tuple(views)
+
+    def post(mod, args, out):
+        rec = mod._fn2_rec
+        rec["out"] = out.detach().clone()
+        if out.requires_grad:
+            out.register_hook(lambda g, rec=rec: rec.__setitem__("gout", g.detach().clone()))
+        calls.append(rec)
+
+    for m in modules:
+        handles += [m.register_forward_pre_hook(pre), m.register_forward_hook(post)]
+    return calls, handles
+
+
+@pytest.mark.gpu
+def test_fused_rows_replayed_inside_one_training_pass(dev):
+    """the pin of the fused training rows without MIOpen between the two sides and without a tolerance to tune.
+    ONE fused training pass of harness.FlowNet2 (WarpDiffNormCat at models.py:133-138 / :145-150, WarpDiffNorm at :157-161 / :170-174) and
+    of harness.FlowNet2C (CorrelationLeakyReLUCat, FlowNetC.py:86-92) is recorded -- the tensors that entered each fused row, the
+    gradient that came back into it, the gradients it sent on --, and exactly those tensors are replayed through the UNFUSED HIP layers
+    under autograd: outputs and flow / feature gradients must be bit-identical."""
+    from harness.flownet2 import FlowNet2
+    from harness.flownet2c import FlowNet2C
+    from harness.train import synthetic_batch
+    from networks.channelnorm_package.channelnorm import ChannelNorm
+    from networks.correlation_package.correlation import Correlation
+    from networks.resample2d_package.resample2d import Resample2d
+    torch.manual_seed(11)
+    net = FlowNet2().to(dev).train()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    inputs, target = synthetic_batch(2, 128, 192, dev, seed=4)
+    calls, handles = _capture_fused_rows([net.warp_cat, net.warp_err])
+    net.fused_training = True
+    out = net(inputs)
+    (out - target).abs().mean().backward()
+    for h in handles:
+        h.remove()
+    assert [type(c["mod"]).__name__ for c in calls] == ["WarpDiffNormCat", "WarpDiffNormCat", "WarpDiffNorm", "WarpDiffNorm"]
+    rs, cn = Resample2d(), ChannelNorm()
+    for c in calls:
+        x, flow = c["inputs"]
+        assert c["gin"][0] is None and c["gin"][1] is not None and "gout" in c        # the pair is the network's input: flow gradient only
+        fl = flow.clone().requires_grad_(True)
+        warped = rs(x[:, 3:], fl)
+        norm = cn(x[:, :3] - warped)
+        unfused = torch.cat((x, warped, fl / net.div_flow, norm), 1) if type(c["mod"]).__name__ == "WarpDiffNormCat" else norm
+        assert torch.equal(unfused.detach(), c["out"]), type(c["mod"]).__name__
+        unfused.backward(c["gout"])
+        assert float(c["gin"][1].abs().max()) > 0
+        assert torch.equal(fl.grad, c["gin"][1]), (type(c["mod"]).__name__, float((fl.grad - c["gin"][1]).abs().max()))
+    # FlowNet2C: the fused correlation epilogue (LeakyReLU + concat) and its backward (mask pass + correlation backward kernels)
+    torch.manual_seed(12)
+    netc = FlowNet2C().to(dev).train()
+    calls, handles = _capture_fused_rows([netc.corr_fused])
+    flows = netc(inputs)
+    sum(f.abs().mean() for f in flows).backward()
+    for h in handles:
+        h.remove()
+    assert len(calls) == 1
+    c = calls[0]
+    a, b, redir = (t.clone().requires_grad_(True) for t in c["inputs"])
+    unfused = torch.cat((redir, F.leaky_relu(Correlation(20, 1, 20, 1, 2, 1)(a, b), 0.1)), 1)
+    assert torch.equal(unfused.detach(), c["out"])
+    unfused.backward(c["gout"])
+    for k, t in enumerate((a, b, redir)):
+        assert c["gin"][k] is not None and float(c["gin"][k].abs().max()) > 0
+        assert torch.equal(t.grad, c["gin"][k]), (k, float((t.grad - c["gin"][k]).abs().max()))
+
+
 @pytest.mark.gpu
 def test_flownet2_trains_through_the_fused_warp(dev):
     """harness.FlowNet2 in grad mode runs WarpDiffNormCat (one kernel forward, one kernel backward) at its two
@@ -348,5 +434,16 @@ def test_flownet2_trains_through_the_fused_warp(dev):
     diff = rel_l2(grads["fused"], grads["unfused"])
     assert diff <= max(1e-3, 10.0 * noise), (diff, noise)
     assert worst(grads["fused"], grads["unfused"]) <= 5e-2
-    grads = {True: grads["fused"]}
-    assert any(float(g.abs().max()) > 0 for n, g in grads[True].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp
+    # The tight bar: every parameter's gradient within 10x what two UNFUSED passes differ by on that parameter.  It
+    # holds whenever no bilinear sample flips between the passes; a flip (either pair of passes shows them equally often,
+    # profiles/r06_forward_reproducibility.log names the op that makes the forward differ from pass to pass) is reported as an
+    # expected failure, not hidden behind a wide tolerance: what the fused rows compute is pinned bit for bit by
+    # test_fused_rows_replayed_inside_one_training_pass on the tensors of one and the same pass.
+    per_noise = {n: float((grads["unfused again"][n] - grads["unfused"][n]).abs().max()) for n in grads["unfused"]}
+    per_diff = {n: float((grads["fused"][n] - grads["unfused"][n]).abs().max()) for n in grads["unfused"]}
+    floor = {n: 1e-6 * float(grads["unfused"][n].abs().max()) for n in grads["unfused"]}
+    loose = [n for n in per_diff if per_diff[n] > 10.0 * max(per_noise[n], floor[n])]
+    assert any(float(g.abs().max()) > 0 for n, g in grads["fused"].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp
+    if loose:
+        pytest.xfail(f"{len(loose)} of {len(per_diff)} parameter gradients beyond 10x the unfused-vs-unfused noise (a bilinear sample "
+                     f"flipped between two passes; worst {max(loose, key=lambda n: per_diff[n] / max(per_noise[n], floor[n]))}); the gross bar above held")
