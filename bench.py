@@ -149,6 +149,13 @@ class HotPath:
             corr(a, b).backward(self.gcorr)
             werr(pair, flow2).backward(self.gnorm)
 
+        # exactly the kernels of step() -- no difference op between warp and norm -- through the modules and autograd: what the
+        # wrappers themselves add (allocations, the autograd nodes, the engine) to the same GPU work
+        def one_same_ops():
+            a.grad = b.grad = img1.grad = flow.grad = None
+            corr(a, b).backward(self.gcorr)
+            norm(warp(img1, flow)).backward(self.gnorm)
+
         def clock(fn):
             for _ in range(3):
                 fn()
@@ -158,7 +165,7 @@ class HotPath:
                 fn()
             torch.cuda.synchronize()
             return time.perf_counter() - t0
-        return clock(one), clock(one_fused)
+        return clock(one), clock(one_fused), clock(one_same_ops)
 
 
 def cpu_baseline(max_seconds=30.0):
@@ -751,7 +758,7 @@ def main():
 
     # The same step through the shipped autograd wrappers (Correlation / Resample2d / ChannelNorm modules, with the
     # difference op of models.py:135 between warp and norm): what a training script pays, allocations included.
-    mod_elapsed, mod_fused_elapsed = hp.module_steps(args.steps)
+    mod_elapsed, mod_fused_elapsed, mod_same_elapsed = hp.module_steps(args.steps)
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
@@ -887,6 +894,8 @@ def main():
             "ms_per_step_eager_with_events": round(eager_elapsed / args.steps * 1e3, 4),
             "ms_per_step_autograd_modules": round(mod_elapsed / args.steps * 1e3, 4),
             "ms_per_step_autograd_fused_rows": round(mod_fused_elapsed / args.steps * 1e3, 4),   # Correlation + WarpDiffNorm (flow gradient only)
+            # the kernels of `ms_per_step` and nothing else (no difference op), through nn.Module + autograd (C++ nodes since round 6)
+            "ms_per_step_autograd_modules_same_kernels": round(mod_same_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

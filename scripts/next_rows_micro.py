@@ -60,6 +60,8 @@ pools = [torch.nn.AvgPool2d(4 << i, 4 << i) for i in range(5)]
 
 
 def ref_loss():
+    for o in outs:
+        o.grad = None
     t = 0.05 * target
     loss, epe = 0, 0
     for i, o in enumerate(outs):
@@ -74,6 +76,8 @@ crit = MultiScaleL1()
 
 
 def fused_loss():
+    for o in outs:
+        o.grad = None                # (as an optimizer's zero_grad(set_to_none=True) does: no accumulation kernels in the timing)
     loss, epe = crit(tuple(outs), target)
     loss.backward()
     return loss, epe
