@@ -43,8 +43,10 @@ at::Tensor primed_workspace(const at::Tensor &like, void *stream, size_t bytes)
 
 struct MultiScaleOp : public torch::autograd::Function<MultiScaleOp> {
     // returns {loss, epe}; epe is not differentiable
+    // want_grads: decided by the caller of apply() (grad mode on and a prediction requires a gradient) -- inside forward grad mode is
+    // off and, when nothing requires a gradient, the node has no edges to ask
     static variable_list forward(AutogradContext *ctx, const at::Tensor &target_, at::TensorList outputs, int64_t start_scale, double div_flow,
-                                 std::vector<double> weights, int64_t norm)
+                                 std::vector<double> weights, int64_t norm, bool want_grads)
     {
         const char *op = "multiscale_loss_cuda.apply";
         const int n = (int)outputs.size();
@@ -56,7 +58,7 @@ struct MultiScaleOp : public torch::autograd::Function<MultiScaleOp> {
         c10::DeviceGuard guard(target_.device());
         at::Tensor target = target_.contiguous();
         const int B = target.size(0), H = target.size(2), W = target.size(3);
-        bool any_grad = false;
+        const bool any_grad = want_grads;
         std::vector<at::Tensor> outs(n), grads;
         const float *optr[6] = {nullptr};
         float *gptr[6] = {nullptr};
@@ -69,7 +71,6 @@ struct MultiScaleOp : public torch::autograd::Function<MultiScaleOp> {
             outs[i] = outputs[i].contiguous();
             optr[i] = outs[i].data_ptr<float>();
             w[i] = (float)weights[i];
-            any_grad = any_grad || ctx->needs_input_grad(1 + i);
         }
         if (any_grad) {
             grads.resize(n);
@@ -97,7 +98,7 @@ struct MultiScaleOp : public torch::autograd::Function<MultiScaleOp> {
     {
         const char *op = "multiscale_loss_cuda.backward";
         const int n = (int)ctx->saved_data["n"].toInt();
-        variable_list result(1 + n + 4);                       // target, n predictions, start_scale, div_flow, weights, norm
+        variable_list result(1 + n + 5);                       // target, n predictions, start_scale, div_flow, weights, norm, want_grads
         auto saved = ctx->get_saved_variables();
         if (saved.empty() || !grad_outputs[0].defined()) return result;
         at::Tensor g = grad_outputs[0];
@@ -123,7 +124,10 @@ struct MultiScaleOp : public torch::autograd::Function<MultiScaleOp> {
 std::vector<at::Tensor> multiscale_apply(const at::Tensor &target, std::vector<at::Tensor> outputs, int64_t start_scale, double div_flow,
                                          std::vector<double> weights, int64_t norm)
 {
-    return MultiScaleOp::apply(target, at::TensorList(outputs), start_scale, div_flow, weights, norm);
+    bool want = false;
+    if (at::GradMode::is_enabled())
+        for (const auto &o : outputs) want = want || o.requires_grad();
+    return MultiScaleOp::apply(target, at::TensorList(outputs), start_scale, div_flow, weights, norm, want);
 }
 
 // the 2*n sums alone (tests, callers without autograd): sums[i] = sum |out_i - t_i|, sums[n+i] = sum of channel 2-norms
