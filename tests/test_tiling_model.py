@@ -162,3 +162,26 @@ def test_resample_backward_atomic_request_model():
     assert r["far_req_merged"] < 0.6 * r["far_req_now"]                 # two corners of a row in one request: about half
     # at 20.5 G requests/s: 36-42 us of atomic-unit time
     assert 36.0 < (flush + far_now) / 20.5e3 < 42.0
+
+
+def test_resample_backward_halo_plane_model():
+    """the atomics-free decomposition of the Resample2d backward (per-tile halo planes written with plain stores + one
+    accumulate pass that overwrites grad_input1) is MODELLED before anything is built (scripts/design/resample_halo_planes.py): with the
+    measured no-flush time of today's kernel (30.8 us: the LDS compare-and-swap scatter is the floor either way), the plane traffic of
+    the bench's flow (38 MB of non-zero 64-byte segments each way) and the measured stream rates it comes out at 50-58 us against 59.9
+    today -- not the <= 45 us that would justify a second kernel, a 57 MB workspace and far-pixel lists.  Not built."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "design")
+    spec = importlib.util.spec_from_file_location("halo", os.path.join(here, "resample_halo_planes.py"))
+    halo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(halo)
+    ns = {}
+    exec(compile(open(os.path.join(here, "resample_atomic_requests.py")).read().split("for shape in (")[0], "req", "exec"), ns)
+    counts = ns["count"](32, 64, 16, b=0)
+    m = halo.model(counts)
+    assert 35.0 < m["plane_MB"] < 41.0 and 60e3 < m["far_entries"] < 85e3 and 55.0 < m["workspace_MB"] < 58.0
+    assert 50.0 < m["total_us"] < 58.0 and m["total_us"] > 45.0          # the decision: above the bar
+    assert m["pass1_us"] >= halo.NO_FLUSH_US                             # the scatter floor is in both designs
+    # brute force of the plane traffic on a small field: non-zero segments = distinct (tile, row, segment) triples, as in the atomic model
+    assert counts["flush_req"] * 8 * 64 == int(round(m["plane_MB"] * 1e6))
