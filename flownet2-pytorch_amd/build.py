@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libflownet2_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-KERNEL_SRCS = ["capi.hip", "channelnorm.hip", "resample2d.hip", "correlation_direct.hip", "correlation_mfma.hip", "correlation_f16x2.hip", "correlation_f16x2_wide.hip", "correlation_f16_fwd.hip", "correlation_f16_bwd.hip", "correlation_f16x2_bwd.hip", "correlation_fused_bwd.hip", "correlation_f16x2_bwd_wide.hip", "correlation_mfma_bwd.hip",
+KERNEL_SRCS = ["capi.hip", "channelnorm.hip", "resample2d.hip", "correlation_direct.hip", "correlation_mfma.hip", "correlation_f16x2.hip", "correlation_f16x2_wide.hip", "correlation_f16_fwd.hip", "correlation_f16_bwd.hip", "correlation_f16x2_bwd.hip", "correlation_fused_bwd.hip", "correlation_f16x2_bwd_wide.hip", "correlation_mfma_bwd.hip", "correlation_mfma_f64.hip",
                "multiscale_loss.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -96,6 +96,14 @@ static int corr_forward_impl(const void *in1, const void *in2, void *out, int64_
         if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
     }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
+    // double tensors on FlowNetC's configuration: v_mfma_f64_16x16x4_f64 (correlation_mfma_f64.hip); AUTO only -- FN2_CORR_DIRECT
+    // keeps selecting the one-thread-per-output kernel
+    if (algo == FN2_CORR_AUTO && corr_mfma_f64_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2) &&
+        aligned(in1, 16) && aligned(in2, 16) && aligned(out, 16) && (out_batch_stride % 2 == 0)) {
+        rc = corr_forward_mfma_f64(static_cast<const double *>(in1), static_cast<const double *>(in2), static_cast<double *>(out), p.out_bs,
+                                   (double)p.slope, B, C, H, W, s);
+        if (!(rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN)) return rc;
+    }
     return corr_forward_direct(in1, in2, out, dtype, p, s);
 }
 
@@ -186,6 +194,12 @@ static int corr_backward_impl(const void *in1, const void *in2, const void *grad
         if (!(algo == FN2_CORR_AUTO && (rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN))) return rc;
     }
     if (algo != FN2_CORR_AUTO && algo != FN2_CORR_DIRECT) return FN2_EINVAL;
+    if (algo == FN2_CORR_AUTO && corr_mfma_f64_applicable(dtype, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2) &&
+        aligned(in1, 16) && aligned(in2, 16) && aligned(grad_out, 16)) {
+        rc = corr_backward_mfma_f64(static_cast<const double *>(in1), static_cast<const double *>(in2), static_cast<const double *>(grad_out),
+                                    static_cast<double *>(grad_in1), static_cast<double *>(grad_in2), B, C, H, W, s);
+        if (!(rc == FN2_EUNSUPPORTED || rc == FN2_EALIGN)) return rc;
+    }
     return corr_backward_direct(in1, in2, grad_out, grad_in1, grad_in2, dtype, p, s);
 }
 

@@ -46,4 +46,9 @@ bool corr_bwd_mfma_f32_applicable(int dtype, int C, int H, int W, int pad, int k
 int corr_backward_mfma_f32(const float *in1, const float *in2, const float *gout, float *g1, float *g2,
                            int B, int C, int H, int W, int md, int tune, hipStream_t s);
 
+// double tensors on the fp64 matrix cores (correlation_mfma_f64.hip): FlowNetC's configuration, md = 20
+bool corr_mfma_f64_applicable(int dtype, int C, int H, int W, int pad, int k, int md, int s1, int s2);
+int corr_forward_mfma_f64(const double *in1, const double *in2, double *out, long out_bs, double slope, int B, int C, int H, int W, hipStream_t s);
+int corr_backward_mfma_f64(const double *in1, const double *in2, const double *gout, double *g1, double *g2, int B, int C, int H, int W, hipStream_t s);
+
 } // namespace fn2
