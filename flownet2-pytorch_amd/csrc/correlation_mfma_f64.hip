@@ -206,12 +206,16 @@ __global__ __launch_bounds__(512, 1) void corr_fwd_mfma_f64(FArgs p)
 // deterministic) and per u over the 2 channel tiles.
 constexpr int BT_X = 32;                                                    // centre pixels per x tile (16 lattice columns per parity)
 constexpr int N_COLS = BT_X / 2 + 2 * DR;                                   // 36 neighbour lattice columns incl. halo
-constexpr int N_ROW = N_COLS, N_PAR = 4 * N_ROW, N_CH = 2 * N_PAR + 9;     // 297: odd channel stride
+constexpr int N_ROW = N_COLS, N_PAR = 4 * N_ROW, N_CH = 2 * N_PAR + 2;     // 290 = 2 mod 32: the 16 channels x 2 k slots of a half-wave read 32 distinct 8-byte banks
 constexpr int BCK = 16;                                                     // channels per tile (MFMA N)
 constexpr int N_EL = BCK * N_CH;                                            // 4752 doubles = 38 KB (single buffer)
-constexpr int G_RS = BT_X + 2;                                              // G tile x stride
-constexpr int G_EL = 16 * D * G_RS;                                         // 11424 doubles = 91 KB: [ai][bi][ti][x]
-constexpr int BNCT = 2, BCG = BNCT * BCK;                                   // channel tiles / channels per task
+// G tile [plane = 4 ai + bi][ti][x]: row stride 33, plane stride 697 = 1 mod 8 -- the gather of a half-wave (16 centre pixels x 2 k slots)
+// then collides 2-way at most (4-way with even strides; no affine layout is conflict-free: a pixel's column and its displacement
+// column move together)
+constexpr int G_RS = BT_X + 1, G_PS = D * G_RS + 4;
+constexpr int G_EL = 16 * G_PS;                                             // 11152 doubles = 89 KB
+static_assert(G_PS % 8 == 1 && G_RS % 32 == 1, "gather bank pattern");
+constexpr int BNCT = 4, BCG = BNCT * BCK;                                   // channel tiles / channels per task
 constexpr int E_RS = BT_X + 1;
 constexpr int E_EL = BCG * 4 * E_RS;
 static_assert(E_EL <= G_EL && (G_EL + N_EL) * 8 <= 163840, "backward LDS budget");
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int ti = hr + 4 * i;
-                if (ti < D) *reinterpret_cast<d2 *>(Gs + (pl * D + ti) * G_RS + 2 * hx) = rg_[h][i];
+                if (ti < D) { double *d = Gs + pl * G_PS + ti * G_RS + 2 * hx; d[0] = rg_[h][i][0]; d[1] = rg_[h][i][1]; }   // (rows are 8-byte aligned only)
             }
         }
     };
@@ -310,44 +314,47 @@ __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
     const int fi = lane & 15, fq = lane >> 4;
     const int g_ai = fi >> 2, g_aj = fi & 3;
     const int n_frag = fi * N_CH + xpar * N_PAR + 4 * a0 + fq;   // + s * N_ROW + 4 v
-    // two accumulators per channel tile (even / odd neighbour blocks v): consecutive MFMAs never wait for each other's result
-    d4 acc[BNCT][2];
+    d4 acc[BNCT];
 #pragma unroll
-    for (int ct = 0; ct < BNCT; ++ct) acc[ct][0] = acc[ct][1] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int ct = 0; ct < BNCT; ++ct) acc[ct] = (d4){0.0, 0.0, 0.0, 0.0};
     int u_lo = 0, u_hi = NV - 1;
     while (u_lo < NV && (4 * rg - DR + 4 * u_lo + 3 < 0)) ++u_lo;
     while (u_hi >= 0 && (4 * rg - DR + 4 * u_hi >= HL)) --u_hi;
-    // (Prefetching the next u's tiles during the MFMAs of the last channel tile was built and measured: the 80 extra live registers
-    // spill -- 256 per lane at two waves per SIMD -- and the kernel gets slower, 684 against 607 us at 8 x 256 x 48 x 64.)
+    // the G operand of (neighbour block v, neighbour row s): Gs[(g_ai * 4 + s) * G_PS + ti_v * G_RS + x], ti_v = 4 v + fq - g_aj; entries
+    // outside the 21-wide band read column 0 and are replaced by zero.  Gathered per (channel tile, s) from LDS -- six 8-byte reads
+    // in front of six 64-cycle MFMAs -- instead of once per u into 48 registers: those registers hold the NEXT u's G tile, whose
+    // loads are then in flight during this u's MFMAs (both at once spill: 256 registers per lane at two waves per SIMD).
+    int g_off[NV];
+    bool g_ok[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int ti = 4 * v + fq - g_aj;
+        g_ok[v] = ti >= 0 && ti < D;
+        g_off[v] = g_ai * 4 * G_PS + (g_ok[v] ? ti : 0) * G_RS + 2 * (4 * a0 + g_aj) + xpar;
+    }
+    if (u_lo <= u_hi) { nbr_load(u_lo, 0); g_load(u_lo); }
     for (int u = u_lo; u <= u_hi; ++u) {
-        nbr_load(u, 0);
-        g_load(u);
         g_write();
         nbr_write();
         __syncthreads();
-        double gfr[NV][4];
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ti = 4 * v + fq - g_aj;
-                const bool ok = ti >= 0 && ti < D;
-                const int x = 2 * (4 * a0 + g_aj) + xpar;
-                const double gv = Gs[((g_ai * 4 + s) * D + (ok ? ti : 0)) * G_RS + x];
-                gfr[v][s] = ok ? gv : 0.0;
-            }
 #pragma unroll
         for (int ct = 0; ct < BNCT; ++ct) {
-            if (ct + 1 < BNCT) nbr_load(u, ct + 1);
+            // in flight during this tile's MFMAs: the other channel tile of u and the next u's G tile, then the next u's first tile
+            if (ct + 1 < BNCT) { nbr_load(u, ct + 1); if (u < u_hi) g_load(u + 1); }
+            else if (u < u_hi) nbr_load(u + 1, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                double nf[NV];
+                double nf[NV], gf[NV];
 #pragma unroll
-                for (int v = 0; v < NV; ++v) nf[v] = Ns[n_frag + s * N_ROW + 4 * v];
+                for (int v = 0; v < NV; ++v) {
+                    const double gv = Gs[g_off[v] + s * G_PS];
+                    gf[v] = g_ok[v] ? gv : 0.0;
+                    nf[v] = Ns[n_frag + s * N_ROW + 4 * v];
+                }
 #pragma unroll
-                for (int v = 0; v < NV; ++v) acc[ct][v & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(gfr[v][s], nf[v], acc[ct][v & 1], 0, 0, 0);
+                for (int v = 0; v < NV; ++v) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(gf[v], nf[v], acc[ct], 0, 0, 0);
             }
-            __syncthreads();                      // the tile has been read
+            __syncthreads();                      // the tiles have been read
             if (ct + 1 < BNCT) {
                 nbr_write();
                 __syncthreads();
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int arow = d_row(lane, r), e_ai = arow >> 2, e_aj = arow & 3;
-                Es[((ct * BCK + fi) * 4 + e_ai) * E_RS + 2 * (4 * a0 + e_aj) + xpar] = acc[ct][0][r] + acc[ct][1][r];
+                Es[((ct * BCK + fi) * 4 + e_ai) * E_RS + 2 * (4 * a0 + e_aj) + xpar] = acc[ct][r];
             }
         __syncthreads();
         const double fC = (double)p.C;

@@ -83,6 +83,18 @@ def fused_loss():
     return loss, epe
 
 
+# what ANY two-launch autograd graph costs at module level on this host (Python call, node construction, the engine's hand-over to its
+# device thread, AccumulateGrad): a tiny multiply + sum and their backward -- the floor under N3's forward + backward, whose two kernels
+# take ~20 us on the GPU
+tiny = torch.randn(64, device=dev, requires_grad=True)
+
+
+def floor_graph():
+    tiny.grad = None
+    (tiny * 2.0).sum().backward()
+
+
+res["autograd_two_op_floor_us"] = timeit(floor_graph)
 res["N3_unfused_us"] = timeit(ref_loss)
 res["N3_fused_us"] = timeit(fused_loss)
 # N2, training half (round 5): the backward of models.py:133-138 -- autograd through cat / div / ChannelNorm / sub / Resample2d against

@@ -14,7 +14,7 @@ from conftest import max_abs
 pytestmark = pytest.mark.gpu
 
 P = (20, 1, 20, 1, 2)
-CASES = [(1, 32, 8, 16), (2, 32, 10, 40), (1, 64, 6, 72), (2, 96, 20, 64), (1, 32, 2, 8), (1, 32, 44, 36), (2, 64, 48, 64)]
+CASES = [(1, 64, 8, 16), (2, 64, 10, 40), (1, 64, 6, 72), (2, 128, 20, 64), (1, 64, 2, 8), (1, 64, 44, 36), (2, 64, 48, 64)]
 
 
 def _data(case, seed_off=0):
@@ -74,8 +74,8 @@ def test_correlation_f64_gradcheck_through_the_module(dev):
     """What double is for: torch.autograd.gradcheck of the Correlation module (central differences in fp64) on the matrix-core path."""
     from networks.correlation_package.correlation import Correlation
     g = torch.Generator().manual_seed(5)
-    a = torch.randn(1, 32, 4, 8, generator=g, dtype=torch.float64).to(dev).requires_grad_()
-    b = torch.randn(1, 32, 4, 8, generator=g, dtype=torch.float64).to(dev).requires_grad_()
+    a = torch.randn(1, 64, 4, 8, generator=g, dtype=torch.float64).to(dev).requires_grad_()
+    b = torch.randn(1, 64, 4, 8, generator=g, dtype=torch.float64).to(dev).requires_grad_()
     sel = torch.randn(1, 441, 4, 8, generator=g, dtype=torch.float64).to(dev)
     corr = Correlation(20, 1, 20, 1, 2, 1)
     assert torch.autograd.gradcheck(lambda x, y: (corr(x, y) * sel).sum(), (a, b), eps=1e-6, atol=1e-7, rtol=1e-6, nondet_tol=0.0)

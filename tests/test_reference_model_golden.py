@@ -114,6 +114,30 @@ def test_flownet2_matches_reference_models_py(dev, golden):
     print(f"FlowNet2 vs reference models.py: fused rows {e_fused:.2e}, separate layers {e_unfused:.2e} of the flow's scale")
 
 
+@pytest.mark.gpu
+def test_flownet2_fp16_close_to_fp32_at_the_baseline_shape(dev, golden):
+    """BASELINE.json configs[3] "fp16 vs fp32" (VERDICT r5 missing #6: the bench timed both and no test compared them): the full FlowNet2
+    stack with half convolution stacks (the custom layers take half tensors as they are: csrc/correlation_f16_fwd.hip, or fp32 operands at
+    the warp sites) against fp32, bs 8 @ 384 x 512, the fixture's weights and inputs, and against the reference's own fp32 result.
+    Bound: half keeps 11 bits; through five stacked networks the end-point difference stays below 2 % of the flow's scale (measured
+    3-6e-3) -- a skipped layer or a wrong cast shows at 1e-1 and more."""
+    from harness.flownet2 import FlowNet2
+    d, inputs, _ = golden
+    inputs = inputs.to(dev)
+    net = fx.fill_state_dict(FlowNet2()).to(dev).eval()
+    with torch.no_grad():
+        y32 = net(inputs)
+        y16 = net.half()(inputs.half())
+    assert y16.dtype == torch.float16 and torch.isfinite(y16).all()
+    scale = float(y32.abs().max())
+    err = float((y16.float() - y32).abs().max()) / scale
+    rms = float((y16.float() - y32).pow(2).mean().sqrt()) / float(y32.pow(2).mean().sqrt())
+    ref = torch.from_numpy(d["flownet2_flow_sub4"]).to(dev)
+    err_ref = float((y16.float()[:, :, ::4, ::4] - ref).abs().max()) / float(ref.abs().max())
+    print(f"FlowNet2 fp16 vs fp32 at bs 8 @ 384x512: max {err:.2e}, rms {rms:.2e} of the flow's scale; vs the reference's fp32 flow {err_ref:.2e}")
+    assert err <= 2e-2 and rms <= 5e-3 and err_ref <= 2e-2, (err, rms, err_ref)
+
+
 def test_fixture_weights_and_inputs_rebuild_without_the_reference():
     """CPU: the harness classes take the by-name weights to the checksums the reference's classes had when the fixture was made (same
     parameter names and shapes), and the inputs rebuild to the stored checksums -- what the GPU tests above start from."""
