@@ -165,7 +165,17 @@ class HotPath:
                 fn()
             torch.cuda.synchronize()
             return time.perf_counter() - t0
-        return clock(one), clock(one_fused), clock(one_same_ops)
+        # the host's floor under ANY module-level step of this shape: two trivial graphs (a multiply + a sum on 64 floats), each with its
+        # own .backward() -- Python call, node construction, the engine's hand-over to its device thread, AccumulateGrad.  A step through
+        # the modules cannot cost less than this on the host it runs on, whatever the kernels take
+        tiny = torch.randn(64, device=self.in1.device, requires_grad=True)
+
+        def floor():
+            tiny.grad = None
+            (tiny * 2.0).sum().backward()
+            tiny.grad = None
+            (tiny * 3.0).sum().backward()
+        return clock(one), clock(one_fused), clock(one_same_ops), clock(floor)
 
 
 def cpu_baseline(max_seconds=30.0):
@@ -758,7 +768,7 @@ def main():
 
     # The same step through the shipped autograd wrappers (Correlation / Resample2d / ChannelNorm modules, with the
     # difference op of models.py:135 between warp and norm): what a training script pays, allocations included.
-    mod_elapsed, mod_fused_elapsed, mod_same_elapsed = hp.module_steps(args.steps)
+    mod_elapsed, mod_fused_elapsed, mod_same_elapsed, mod_floor_elapsed = hp.module_steps(args.steps)
 
     if rank == 0:
         per_op_ms = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in events.items()}
@@ -896,6 +906,8 @@ def main():
             "ms_per_step_autograd_fused_rows": round(mod_fused_elapsed / args.steps * 1e3, 4),   # Correlation + WarpDiffNorm (flow gradient only)
             # the kernels of `ms_per_step` and nothing else (no difference op), through nn.Module + autograd (C++ nodes since round 6)
             "ms_per_step_autograd_modules_same_kernels": round(mod_same_elapsed / args.steps * 1e3, 4),
+            # ... and what two .backward() calls of trivial graphs cost on this host (no kernels to speak of): the floor under both
+            "ms_per_step_autograd_host_floor": round(mod_floor_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -38,4 +38,11 @@ for (B, C, H, W) in ((1, 256, 56, 128), (8, 256, 56, 128), (4, 256, 48, 64), (8,
         gh = go.half(); h1 = torch.empty_like(ah); h2 = torch.empty_like(ah)
         line += "  bwd half %.1f us" % timeit(lambda: fn2_capi.correlation_backward(ah, bh, gh, 20, 1, 20, 1, 2, out=(h1, h2)))
         line += " (general kernel %.1f us)" % timeit(lambda: fn2_capi.correlation_backward(ah, bh, gh, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT, out=(h1, h2)), n=3)
+    if W <= 64 and B == 8:   # double tensors: the fp64 matrix-core kernels (round 6) against the one-thread-per-output kernel
+        ad, bd_, gd = a.double(), b.double(), go.double()
+        od = torch.empty(B, 441, H, W, device=dev, dtype=torch.float64); d1 = torch.empty_like(ad); d2 = torch.empty_like(ad)
+        line += "  fwd double %.1f us" % timeit(lambda: fn2_capi.correlation_forward(ad, bd_, 20, 1, 20, 1, 2, out=od), n=10)
+        line += " (general kernel %.1f us)" % timeit(lambda: fn2_capi.correlation_forward(ad, bd_, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT, out=od), n=3)
+        line += "  bwd double %.1f us" % timeit(lambda: fn2_capi.correlation_backward(ad, bd_, gd, 20, 1, 20, 1, 2, out=(d1, d2)), n=10)
+        line += " (general kernel %.1f us)" % timeit(lambda: fn2_capi.correlation_backward(ad, bd_, gd, 20, 1, 20, 1, 2, algo=fn2_capi.FN2_CORR_DIRECT, out=(d1, d2)), n=2)
     print(line)
