@@ -26,17 +26,21 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 20260924
 # (name suffix, B, C, H, W): 64 channels = the smallest channel count the kernels take (two 32-channel steps, one 64-channel group);
 # 256 channels = FlowNetC's conv3 (eight steps of the forward, four channel-group tasks per row group in the backward; ~20 minutes)
-CASES = [("1x64x48x64", 1, 64, 48, 64), ("1x256x48x64", 1, 256, 48, 64)]
+# 56 x 128 (round 6): Sintel-size conv3 -- the task tables of the WIDE kernels (column windows, row-group pairs per B row block,
+# seven row groups = an odd count, windows that end at the right border)
+CASES = [("1x64x48x64", 1, 64, 48, 64), ("1x256x48x64", 1, 256, 48, 64), ("1x64x56x128", 1, 64, 56, 128)]
 PLANES = sorted(set([0, 20, 420, 440, 220, 10, 210, 230, 430, 21, 41, 399, 419] + list(range(7, 441, 23))))[:32]
 CHANNELS = [0, 3, 7, 17, 31, 32, 48, 63]
 
 
-def seed_of(C):
+def seed_of(C, W=64):
+    if W != 64:
+        return SEED + 1000 + W
     return SEED if C == 64 else SEED + C      # (the 64-channel fixture was drawn from SEED itself)
 
 
 def make_inputs(B, C, H, W):
-    rng = np.random.default_rng(seed_of(C))
+    rng = np.random.default_rng(seed_of(C, W))
     in1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
     in2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
     gout = rng.standard_normal((B, 441, H, W)).astype(np.float32)
@@ -67,7 +71,7 @@ def one(name, B, C, H, W):
     g1, g2 = ref.corr_bwd(in1, in2, gout, pad, k, md, s1, s2)
     print("backward %.0f s" % (time.time() - t), flush=True)
     o64 = out.astype(np.float64)
-    d = dict(seed=np.int64(seed_of(C)), shape=np.array([B, C, H, W], np.int32), params=np.array([pad, k, md, s1, s2], np.int32),
+    d = dict(seed=np.int64(seed_of(C, W)), shape=np.array([B, C, H, W], np.int32), params=np.array([pad, k, md, s1, s2], np.int32),
              input_checksum=checksum(in1, in2, gout), planes=np.array(PLANES, np.int32), channels=np.array(channels, np.int32),
              out_planes=out[:, PLANES], out_sum=o64.sum(axis=(0, 2, 3)), out_sumsq=(o64 * o64).sum(axis=(0, 2, 3)),
              g1_channels=g1[:, channels], g2_channels=g2[:, channels],
