@@ -642,6 +642,8 @@ def main():
     ap.add_argument("--pmc", choices=("auto", "on", "off"), default="auto",
                     help="measure the graded kernel's fabric traffic in THIS run (two rocprofv3 --pmc passes over a tiny child "
                          "process, one GPU only); auto = on where rocprofv3 is installed")
+    ap.add_argument("--placement", choices=("auto", "on", "off"), default="auto",
+                    help="untimed set-up: re-place the step's buffers when the step is > 10 %% above the sum of its kernels (auto), always try (on), never (off)")
     ap.add_argument("--model-steps", type=int, default=20)
     ap.add_argument("--model-warmup", type=int, default=5)
     ap.add_argument("--model-timeout", type=float, default=240.0, help="seconds after which the FlowNet2C pass is abandoned")
@@ -670,6 +672,45 @@ def main():
     for _ in range(100):
         hp.step()
     torch.cuda.synchronize()
+    # Placement of the step's buffers, chosen in the UNTIMED set-up (round 6).  About every second box of the pool runs the raw step 20-25 %
+    # slower at identical kernel times; on such a box the same kernels through the autograd modules -- whose tensors lie elsewhere -- ran at
+    # the fast boxes' speed (0.184 against 0.249 ms, profiles/r06_a_*): where the buffers lie matters there, and only there (on a fast box
+    # four placements are within 1 %, profiles/r06_c_placement_probe.log).  So: time the step as allocated; if it is more than 10 % above
+    # the sum of its kernels' own durations (the slow-box signature), move every tensor to a fresh allocation -- up to three times -- and
+    # keep the fastest placement.  Same tensors, same kernels, same K timed steps afterwards; what was tried is in the JSON line.
+    def _clock_steps(n=40):
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            hp.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t_) / n * 1e3
+    placement = {"tried_ms_per_step": [round(_clock_steps(), 4)], "kernel_sum_ms": None, "chosen": 0}
+    if args.placement != "off":
+        ev_ = {}
+        for _ in range(10):
+            hp.step(ev_)
+        torch.cuda.synchronize()
+        ksum = sum(sum(s_.elapsed_time(e_) for s_, e_ in v) / len(v) for v in ev_.values())
+        placement["kernel_sum_ms"] = round(ksum, 4)
+        if args.placement == "on" or placement["tried_ms_per_step"][0] > 1.10 * ksum:
+            names = [n_ for n_, t_ in vars(hp).items() if torch.is_tensor(t_) and t_.numel()]
+            best = {n_: getattr(hp, n_) for n_ in names}
+            held = []
+            for trial in range(3):
+                held.append({n_: getattr(hp, n_) for n_ in names})           # the old blocks stay allocated: the clones must land elsewhere
+                for n_ in names:
+                    setattr(hp, n_, getattr(hp, n_).clone())
+                for _ in range(20):
+                    hp.step()
+                placement["tried_ms_per_step"].append(round(_clock_steps(), 4))
+                if placement["tried_ms_per_step"][-1] < min(placement["tried_ms_per_step"][:-1]):
+                    best = {n_: getattr(hp, n_) for n_ in names}
+                    placement["chosen"] = trial + 1
+            for n_, t_ in best.items():
+                setattr(hp, n_, t_)
+            del held
+            torch.cuda.empty_cache()
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         hp.step()
     torch.cuda.synchronize()
@@ -901,6 +942,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "launch": "hipGraph replay of the step" if graph is not None else "eager launches",
+            "placement_autotune": placement,   # untimed set-up: step time per buffer placement tried, the one the timed steps ran with
             "ms_per_step_eager_with_events": round(eager_elapsed / args.steps * 1e3, 4),
             "ms_per_step_autograd_modules": round(mod_elapsed / args.steps * 1e3, 4),
             "ms_per_step_autograd_fused_rows": round(mod_fused_elapsed / args.steps * 1e3, 4),   # Correlation + WarpDiffNorm (flow gradient only)
