@@ -1148,7 +1148,9 @@ __global__ __launch_bounds__(NT, 8) void resample_bwd_c3x(const C3xArgs p)
         for (int i = tid; i < CELLS * 3; i += NT) aw[i] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);   // all of that goes out before the wave waits for its flow sample
     int offx, offy;
-    tile_window_offset(tfs, offx, offy, 16);
+    // 16-px steps where a window is flushed (a flushed row is then exactly six 64-byte segments); the gather-only instantiations have no
+    // flush to align and keep the finer 4-px steps (2 instead of 8 px of the margin lost at worst: ADVICE r5)
+    tile_window_offset(tfs, offx, offy, SCATTER ? 16 : 4);
     const int wx0 = X0 - R + offx, wy0 = Y0 - R + offy;
     if (SCATTER) __syncthreads();
     stamp(1);
