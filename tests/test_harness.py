@@ -439,10 +439,16 @@ def test_flownet2_trains_through_the_fused_warp(dev):
     # profiles/r06_forward_reproducibility.log names the op that makes the forward differ from pass to pass) is reported as an
     # expected failure, not hidden behind a wide tolerance: what the fused rows compute is pinned bit for bit by
     # test_fused_rows_replayed_inside_one_training_pass on the tensors of one and the same pass.
+    scale = {n: max(float(grads["unfused"][n].abs().max()), 1e-30) for n in grads["unfused"]}
     per_noise = {n: float((grads["unfused again"][n] - grads["unfused"][n]).abs().max()) for n in grads["unfused"]}
     per_diff = {n: float((grads["fused"][n] - grads["unfused"][n]).abs().max()) for n in grads["unfused"]}
-    floor = {n: 1e-6 * float(grads["unfused"][n].abs().max()) for n in grads["unfused"]}
-    loose = [n for n in per_diff if per_diff[n] > 10.0 * max(per_noise[n], floor[n])]
+    # one pair of passes is a poor estimate of a single parameter's noise (two passes now and then agree to the bit on most of the
+    # network): a parameter's noise level is at least the network-wide median of the relative noise, and at least 1e-5 of its gradient
+    rel = sorted(per_noise[n] / scale[n] for n in per_noise)
+    typical = max(rel[len(rel) // 2], 1e-5)
+    level = {n: max(per_noise[n], typical * scale[n]) for n in per_noise}
+    loose = [n for n in per_diff if per_diff[n] > 10.0 * level[n]]
+    floor = level
     assert any(float(g.abs().max()) > 0 for n, g in grads["fused"].items() if n.startswith("flownetc."))   # gradient reaches the first net through the warp
     if loose:
         pytest.xfail(f"{len(loose)} of {len(per_diff)} parameter gradients beyond 10x the unfused-vs-unfused noise (a bilinear sample "
