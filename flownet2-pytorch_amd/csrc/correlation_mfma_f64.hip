@@ -208,7 +208,7 @@ constexpr int BT_X = 32;                                                    // c
 constexpr int N_COLS = BT_X / 2 + 2 * DR;                                   // 36 neighbour lattice columns incl. halo
 constexpr int N_ROW = N_COLS, N_PAR = 4 * N_ROW, N_CH = 2 * N_PAR + 2;     // 290 = 2 mod 32: the 16 channels x 2 k slots of a half-wave read 32 distinct 8-byte banks
 constexpr int BCK = 16;                                                     // channels per tile (MFMA N)
-constexpr int N_EL = BCK * N_CH;                                            // 4752 doubles = 38 KB (single buffer)
+constexpr int N_EL = BCK * N_CH;                                            // 4640 doubles = 37 KB per buffer; two buffers (channel tile ct in buffer ct & 1)
 // G tile [plane = 4 ai + bi][ti][x]: row stride 33, plane stride 697 = 1 mod 8 -- the gather of a half-wave (16 centre pixels x 2 k slots)
 // then collides 2-way at most (4-way with even strides; no affine layout is conflict-free: a pixel's column and its displacement
 // column move together)
@@ -218,7 +218,7 @@ static_assert(G_PS % 8 == 1 && G_RS % 32 == 1, "gather bank pattern");
 constexpr int BNCT = 4, BCG = BNCT * BCK;                                   // channel tiles / channels per task
 constexpr int E_RS = BT_X + 1;
 constexpr int E_EL = BCG * 4 * E_RS;
-static_assert(E_EL <= G_EL && (G_EL + N_EL) * 8 <= 163840, "backward LDS budget");
+static_assert(BNCT % 2 == 0 && E_EL <= G_EL && (G_EL + 2 * N_EL) * 8 <= 163840, "backward LDS budget");
 
 struct BArgs {
     const double *nbr[2];
@@ -229,7 +229,7 @@ struct BArgs {
 
 __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
 {
-    __shared__ __attribute__((aligned(16))) double smem[G_EL + N_EL];
+    __shared__ __attribute__((aligned(16))) double smem[G_EL + 2 * N_EL];
     double *Gs = smem, *Ns = smem + G_EL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
         for (int k = 0; k < 8; ++k)
             rn[k] = ok ? *reinterpret_cast<const d2 *>(nbr_n + (long)(ct * BCK + 2 * k + (wave >> 2)) * HW + (long)(2 * il + py) * p.W + s_xb) : (d2){0.0, 0.0};
     };
-    auto nbr_write = [&]() {
+    auto nbr_write = [&](int buf) {
         if (lane < N_COLS) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                double *d = Ns + (2 * k + (wave >> 2)) * N_CH + s_bi * N_ROW + lane;
+                double *d = Ns + buf * N_EL + (2 * k + (wave >> 2)) * N_CH + s_bi * N_ROW + lane;
                 d[0] = rn[k][0];
                 d[N_PAR] = rn[k][1];
             }
@@ -335,13 +335,14 @@ __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
     if (u_lo <= u_hi) { nbr_load(u_lo, 0); g_load(u_lo); }
     for (int u = u_lo; u <= u_hi; ++u) {
         g_write();
-        nbr_write();
+        nbr_write(0);
         __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < BNCT; ++ct) {
-            // in flight during this tile's MFMAs: the other channel tile of u and the next u's G tile, then the next u's first tile
-            if (ct + 1 < BNCT) { nbr_load(u, ct + 1); if (u < u_hi) g_load(u + 1); }
+            // in flight during this tile's MFMAs: the next channel tile of u (and, once per u, the next u's G tile), then the next u's first tile
+            if (ct + 1 < BNCT) nbr_load(u, ct + 1);
             else if (u < u_hi) nbr_load(u + 1, 0);
+            if (ct == 0 && u < u_hi) g_load(u + 1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 double nf[NV], gf[NV];
@@ -349,16 +350,13 @@ __global__ __launch_bounds__(512, 1) void corr_bwd_mfma_f64(BArgs p)
                 for (int v = 0; v < NV; ++v) {
                     const double gv = Gs[g_off[v] + s * G_PS];
                     gf[v] = g_ok[v] ? gv : 0.0;
-                    nf[v] = Ns[n_frag + s * N_ROW + 4 * v];
+                    nf[v] = Ns[(ct & 1) * N_EL + n_frag + s * N_ROW + 4 * v];
                 }
 #pragma unroll
                 for (int v = 0; v < NV; ++v) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(gf[v], nf[v], acc[ct], 0, 0, 0);
             }
-            __syncthreads();                      // the tiles have been read
-            if (ct + 1 < BNCT) {
-                nbr_write();
-                __syncthreads();
-            }
+            if (ct + 1 < BNCT) nbr_write((ct + 1) & 1);   // the other buffer: last read two tiles ago
+            __syncthreads();                              // this tile has been read, the next one is complete
         }
     }
     // ---- epilogue: acc[ct][r] = g[centre pixel d_row(lane, r) of block a0][channel 16 ct + (lane & 15)] -> LDS [ch][ai][x] -> rows
