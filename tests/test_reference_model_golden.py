@@ -9,9 +9,10 @@ the reference on the CPU, tests/test_harness_pin.py) running on the HIP layers -
 reference's flows, loss and parameter gradients.
 
 Tolerances: the two sides differ in the convolution backend (MIOpen here, oneDNN there) and in the summation order of the layers;
-a perturbation of every weight by 3e-7 moves these outputs by 2e-6 of their scale (measured when the fixture was made), so 1e-4 of the
-scale leaves two orders of magnitude for fp32 convolution differences and none for a wrong layer (a skipped LeakyReLU, a transposed
-displacement or a shifted warp changes the flow by 1e-1 of its scale and more)."""
+a perturbation of every weight by 3e-7 moves these outputs by 2e-6 of their scale (measured when the fixture was made).  Measured on
+the GPU (round 6): FlowNet2C's flow 8.5e-7, FlowNet2's 2.2e-6 of the flow's scale (fused rows and separate layers alike), gradient
+norms 1.3e-4 (the L1 loss's sign() flips single elements).  Bars: 1e-5 of the scale for every flow (VERDICT r5's figure), 1e-4 for loss
+and EPE, 1e-3 for gradient norms -- a skipped LeakyReLU, a transposed displacement or a shifted warp changes the flow by 1e-1 and more."""
 import os
 import sys
 
@@ -25,7 +26,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import refmodel_fixture as fx  # noqa: E402
 
 FIXTURE = os.path.join(GOLDEN, "refmodels_8x384x512.npz")
-TOL = 1e-4
+TOL = 1e-5          # flows, of the flow's scale
+TOL_LOSS = 1e-4     # loss and EPE, relative
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +76,7 @@ def test_flownet2c_matches_reference_models_py(dev, golden):
             ref = d[f"flownet2c_train_flow{i}"]
             assert float(np.abs(f.detach().cpu().numpy() - ref).max()) <= TOL * float(np.abs(ref).max()), (fused, i)
         rl, re = (float(v) for v in d["flownet2c_loss_epe"])
-        assert abs(float(loss.detach()) - rl) <= TOL * rl and abs(float(epe.detach()) - re) <= TOL * re, (float(loss.detach()), rl, float(epe.detach()), re)
+        assert abs(float(loss.detach()) - rl) <= TOL_LOSS * rl and abs(float(epe.detach()) - re) <= TOL_LOSS * re, (float(loss.detach()), rl, float(epe.detach()), re)
         # parameter gradients: L2 norm, sum |.| and the first 16 values of every parameter against the reference's autograd through
         # the reference's own Functions.  (sign() in the L1 loss makes single elements jump where |out - t| is at rounding level:
         # the bar on norms is 1e-3, on the leading values 1e-3 of the tensor's largest gradient)
