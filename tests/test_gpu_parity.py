@@ -333,7 +333,7 @@ def test_warp_diff_norm_cat_backward(dev, oracle, shape, bilinear):
     UNFUSED HIP layers (Resample2d, ChannelNorm, cat, the division) on the same inputs -- grad_flow bit-identical, the pair's
     gradient to the order of the fp32 atomics --, with and without the pair's gradient (without: gather only, no atomics), through
     the ctypes entry point and through the differentiable module; shapes the tiled kernel does not take (C != 3, ragged widths) use
-    the one-lane-per-pixel kernel.  On a small case also against the oracle's composition of the reference kernels."""
+    the one-lane-per-pixel kernel.  Also against the oracle's composition of the reference kernels (every item of the small shapes, one item of the BASELINE shape)."""
     import fn2_capi
     from networks.resample2d_package.resample2d import Resample2d, WarpDiffNormCat
     from networks.channelnorm_package.channelnorm import ChannelNorm
@@ -366,19 +366,21 @@ def test_warp_diff_norm_cat_backward(dev, oracle, shape, bilinear):
     assert float((gp[:, C:] - x.grad[:, C:]).abs().max()) <= 5e-6 * sx
     gp, gf = fn2_capi.warp_diff_norm_cat_backward(x3, f0.to(dev), out.detach(), gcat, 20.0, bilinear, False)
     assert gp is None and torch.equal(gf, f.grad)
-    if B * C * H * W <= 3 * 3 * 50 * 132:
-        # oracle composition: channelnorm_kernel.cu:63-96 then resample2d_kernel.cu:75-198 (both ignore `bilinear`)
-        xn, fn, gn = x0.numpy(), f0.numpy(), gcat.cpu().numpy()
-        warped = oracle.resample_fwd(np.ascontiguousarray(xn[:, C:]), fn, 1, bilinear)
-        diff = xn[:, :C] - warped
-        nrm = oracle.chnorm_fwd(diff)
-        gdiff = oracle.chnorm_bwd(diff, nrm, np.ascontiguousarray(gn[:, 3 * C + 2:3 * C + 3]))
-        gw = gn[:, 2 * C:3 * C] - gdiff
-        rimg, rflow = oracle.resample_bwd(np.ascontiguousarray(xn[:, C:]), fn, np.ascontiguousarray(gw), 1, True)
-        rflow = rflow + gn[:, 3 * C:3 * C + 2] * (np.float32(1.0) / np.float32(20.0))
-        assert max_abs(f2.grad.cpu().numpy(), rflow) <= 1e-5 * max(1.0, float(np.abs(rflow).max()))
-        assert max_abs(x2.grad[:, :C].cpu().numpy(), gn[:, :C] + gdiff) <= 1e-5 * max(1.0, float(np.abs(gdiff).max()))
-        assert max_abs(x2.grad[:, C:].cpu().numpy(), gn[:, C:2 * C] + rimg) <= 2e-5 * max(1.0, float(np.abs(rimg).max()))
+    # oracle composition: channelnorm_kernel.cu:63-96 then resample2d_kernel.cu:75-198 (both ignore `bilinear`) -- on every batch item of
+    # the small shapes, on the first item of the BASELINE shape (round 6: the fused backward at 8 x 3 x 384 x 512 is no longer checked
+    # against the unfused HIP layers only; the layers have no cross-item dependence)
+    ns = slice(0, B) if B * C * H * W <= 3 * 3 * 50 * 132 else slice(0, 1)
+    xn, fn, gn = x0.numpy()[ns], f0.numpy()[ns], gcat.cpu().numpy()[ns]
+    warped = oracle.resample_fwd(np.ascontiguousarray(xn[:, C:]), fn, 1, bilinear)
+    diff = xn[:, :C] - warped
+    nrm = oracle.chnorm_fwd(diff)
+    gdiff = oracle.chnorm_bwd(diff, nrm, np.ascontiguousarray(gn[:, 3 * C + 2:3 * C + 3]))
+    gw = gn[:, 2 * C:3 * C] - gdiff
+    rimg, rflow = oracle.resample_bwd(np.ascontiguousarray(xn[:, C:]), fn, np.ascontiguousarray(gw), 1, True)
+    rflow = rflow + gn[:, 3 * C:3 * C + 2] * (np.float32(1.0) / np.float32(20.0))
+    assert max_abs(f2.grad[ns].cpu().numpy(), rflow) <= 1e-5 * max(1.0, float(np.abs(rflow).max()))
+    assert max_abs(x2.grad[ns, :C].cpu().numpy(), gn[:, :C] + gdiff) <= 1e-5 * max(1.0, float(np.abs(gdiff).max()))
+    assert max_abs(x2.grad[ns, C:].cpu().numpy(), gn[:, C:2 * C] + rimg) <= 2e-5 * max(1.0, float(np.abs(rimg).max()))
 
 
 @pytest.mark.parametrize("shape", [(8, 3, 384, 512), (2, 3, 40, 64), (3, 3, 50, 132), (2, 2, 17, 33), (1, 1, 16, 36), (1, 3, 100, 200)])
