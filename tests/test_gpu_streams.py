@@ -114,3 +114,62 @@ def test_layers_replay_from_a_hip_graph():
                 assert float((captured[k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), (seed, k)
             else:
                 assert torch.equal(captured[k], v), (seed, k)
+
+
+def test_modules_and_loss_replay_from_a_hip_graph():
+    """Round 6: the MODULE path -- the C++ autograd nodes of Correlation / Resample2d / ChannelNorm, the fused rows and the MultiScale loss
+    node (whose workspace is created, zero-filled and cached inside the capture) -- forward AND backward inside one hipGraph: warm-up on a
+    side stream, capture, then replays on new input values in the same buffers must equal the eager modules."""
+    from losses_fused import MultiScale
+    from networks.channelnorm_package.channelnorm import ChannelNorm
+    from networks.correlation_package.correlation import Correlation, CorrelationLeakyReLUCat
+    from networks.resample2d_package.resample2d import Resample2d, WarpDiffNormCat
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    B, C, H, W, HI, WI = 2, 64, 24, 32, 128, 192
+    a, b, redir = r(B, C, H, W).requires_grad_(), r(B, C, H, W).requires_grad_(), r(B, 8, H, W).requires_grad_()
+    pair, flow = r(B, 6, HI, WI), (r(B, 2, HI, WI) * 3).requires_grad_()
+    target = r(B, 2, HI, WI) * 5
+    outs = [(r(B, 2, HI // (4 << i), WI // (4 << i)) * 0.3).requires_grad_() for i in range(5)]
+    leaves = [a, b, redir, flow] + outs
+    corr, fused = Correlation(20, 1, 20, 1, 2, 1), CorrelationLeakyReLUCat(20, 1, 20, 1, 2, 0.1)
+    warp, norm, wcat, crit = Resample2d(), ChannelNorm(), WarpDiffNormCat(20.0), MultiScale(None)
+
+    def fwd_bwd():
+        for t in leaves:
+            t.grad = None
+        o = corr(a, b)
+        f = fused(a, b, redir)
+        n = norm(pair[:, :3] - warp(pair[:, 3:].contiguous(), flow))
+        c = wcat(pair, flow)
+        loss, epe = crit(tuple(outs), target)
+        (o.square().mean() + f.mean() + n.mean() + c.square().mean() + loss).backward()
+        return [o.detach(), f.detach(), n.detach(), c.detach(), loss.detach(), epe.detach()] + [t.grad for t in leaves]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    for t in leaves:
+        t.grad = None
+    with torch.cuda.graph(graph):
+        captured = fwd_bwd()
+    for seed in (32, 33):
+        g2 = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for t in [a, b, redir, pair, target] + outs:
+                t.copy_(torch.randn(t.shape, generator=g2).to(dev) * (0.3 if t.shape[1] == 2 and t is not target else 1.0))
+            flow.copy_(torch.randn(flow.shape, generator=g2).to(dev) * 3)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in captured]
+        eager = fwd_bwd()
+        torch.cuda.synchronize()
+        for i, (x, y) in enumerate(zip(got, eager)):
+            assert x.shape == y.shape and torch.isfinite(x).all(), (seed, i)
+            assert float((x - y).abs().max()) <= 1e-5 * max(1e-6, float(y.abs().max())), (seed, i, float((x - y).abs().max()))
