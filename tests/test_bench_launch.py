@@ -121,6 +121,10 @@ def test_bench_gpus_8_line_explains_itself():
     assert len(line["per_rank"]) == 8
     for p in line["per_rank"]:
         assert p["finite"] and p["ms_per_step"] > 0 and p["image_pairs_per_s"] > 0 and p["corr_fwd_us_warm"] > 0 and p["copy_GBps_torch"] > 0
+        # round 6: where the rank ran -- the GPU's slot and the host cores it pinned itself to
+        assert {"pci_bus_id", "numa_node", "xgmi_hive_id", "hip_visible_devices", "cpu_cores", "pid"} <= set(p)
+    assert len({p["cpu_cores"] for p in line["per_rank"]}) == 8                 # eight disjoint core sets
+    assert line["launch"].startswith("hipGraph") and "placement_autotune" in line
     slowest = max(p["ms_per_step"] for p in line["per_rank"])
     assert abs(line["ms_per_step"] - slowest) <= 0.25 * slowest + 0.05       # the step time is the slowest rank's (barriers aside)
     assert 0 < line["rank_balance_fastest_over_slowest"] <= 1.0
