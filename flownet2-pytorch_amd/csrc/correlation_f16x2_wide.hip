@@ -46,9 +46,12 @@ constexpr int WPARS = CK * RS;           // 19456
 constexpr int WTERM = 2 * WPARS;         // 38912
 constexpr int WBUF = 2 * WTERM;          // 77824: one step
 constexpr int WLDS = 2 * WBUF;           // 155648: two steps
-// epilogue image: 32 planes (row group, ai, bi) x 26 rows (21 + slack) x 32 floats, plane stride + 12 floats: the scatter's 64
-// lanes then collide 2-way at most and the 16-byte row reads not at all (scripts/design/epilogue_banks.py)
-constexpr int WO_RS = 32, WO_PS = O_DP * WO_RS + 12;
+// epilogue image: 32 planes (row group, ai, bi) x 26 rows (21 + slack) x 32 floats, the 16-byte slots of a row rotated by 8 ai floats.  A
+// ds_write_b32 is serviced in two groups of 32 lanes on 32 banks, and a wave writes one x parity only: 2-way is the floor; this layout
+// reaches it, the 16-byte row reads (four groups of 16 lanes, 64 banks) are conflict-free.  (The first round-6 layout -- plane stride + 12
+// floats, no rotation -- had been checked against a 64-bank model of the write: 4-way in fact, 4.3 M bank-conflict cycles per launch at
+// 8 x 256 x 56 x 128, profiles/r06_v_sq_wide.log.)
+constexpr int WO_RS = 32, WO_PS = O_DP * WO_RS;
 static_assert((32 * WO_PS + O_SLACK * WO_RS) * 4 <= WLDS, "epilogue image must fit the operand buffers");
 static_assert(WTERM + (NSLOT - 1) * 32 + 16 * RS + 8 * 3 + 3 * RS < 65536, "fragment offsets are ds_read immediates");
 
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2_wide(ArgsW p)
             const int tj = 4 * (tk.db - r) + bi - ai, IL = 4 * (tk.rg0 + r) + ai;   // u of row group r is db - r
             if (tj < 0 || tj >= D || IL < 0 || IL >= HL) continue;                                // the whole plane lies outside the volume (uniform)
             const int y = 2 * IL + tk.py;
-            const float *src = Os + (16 * r + wave) * WO_PS + (O_SLACK + g) * WO_RS + xg;   // + 8 i rows: immediates
+            const float *src = Os + (16 * r + wave) * WO_PS + (O_SLACK + g) * WO_RS + ((xg + 8 * ai) & 31);   // + 8 i rows: immediates
             f4 vals[NR];
 #pragma unroll
             for (int i = 0; i < NR; ++i) vals[i] = *reinterpret_cast<const f4 *>(src + 8 * i * WO_RS);
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(1024, 4) void corr_fwd_f16x2_wide(ArgsW p)
         const int rbase = (16 * rsel + 4 * e_ai + e_bi) * WO_PS + (O_SLACK + DR - 12 - e_aj) * WO_RS;     // row of (dm = -3, r = 0)
 #pragma unroll
         for (int ab = 0; ab < 2; ++ab) {
-            float *dst = Os + rbase + (8 * (2 * half + ab) + 2 * e_aj + xpar);
+            float *dst = Os + rbase + ((8 * (2 * half + ab) + 2 * e_aj + xpar + 8 * e_ai) & 31);
 #pragma unroll
             for (int dmi = 0; dmi < NB; ++dmi)
 #pragma unroll
