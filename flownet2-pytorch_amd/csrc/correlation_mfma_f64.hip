@@ -27,11 +27,13 @@ __device__ __forceinline__ int d_row(int lane, int r) { return 4 * r + (lane >> 
 
 // ------------------------------------------------------------------------------------------------ forward
 constexpr int TILE_X = 64;                                                  // image pixels per x tile (32 lattice columns per parity)
-constexpr int A_ROW = 36, A_PAR = 4 * A_ROW, A_CH = 2 * A_PAR + 8;          // elements: [ch][xpar][row][col]
+constexpr int A_ROW = 36, A_PAR = 4 * A_ROW, A_CH = 2 * A_PAR + 16;         // elements: [ch][xpar][row][col]; 304 = 16 mod 32: the two k slots of a
+                                                                            // half-wave's 8-byte fragment read (2 x 32 lanes, 64 banks) fall on disjoint halves
 constexpr int B_COLS = TILE_X / 2 + 2 * DR;                                 // 52
-constexpr int B_ROW = B_COLS, B_PAR = 4 * B_ROW, B_CH = 2 * B_PAR + 8;
+constexpr int B_ROW = B_COLS, B_PAR = 4 * B_ROW, B_CH = 2 * B_PAR + 16;     // 432 = 16 mod 32
 constexpr int FCK = 8;                                                      // channels per chunk (2 k-steps of 4)
-constexpr int F_BUF = FCK * (A_CH + B_CH);                                  // 5760 doubles = 46 KB; two buffers
+constexpr int F_BUF = FCK * (A_CH + B_CH);                                  // 5888 doubles = 47 KB; two buffers
+static_assert(A_CH % 32 == 16 && B_CH % 32 == 16, "k-slot halves must be 16 eight-byte units apart");
 constexpr int O_RS = 66;                                                    // epilogue x stride
 constexpr int O_EL = 8 * D * O_RS + 64;                                     // 8 planes per pass (two passes) + one spare row
 constexpr int F_LDS = (2 * F_BUF > O_EL ? 2 * F_BUF : O_EL);
